@@ -1,0 +1,157 @@
+# -*- coding: utf-8 -*-
+"""Generate the golden vectors under tests/golden/ from the reference implementation.
+
+Runs ONLY in the build container (it imports /root/reference; the GPU box has no copy).
+The outputs are data: inputs and the reference's outputs.  No reference source is stored.
+
+The reference is imported as-is with two in-process shims for ordinary Python errors on
+this image:
+  * ``np.float`` / ``np.int`` aliases (removed from NumPy >= 1.24; parameters.py:11 etc.)
+  * a stub ``numba`` module whose ``jit`` returns the function unchanged (numba is not
+    installed), so the four loop nests run as plain NumPy-scalar Python.
+``SparseGaP.step()`` raises NameError in the reference (sparse_gap.py:127 reads a bare
+``S_hat``).  To capture its evident intent without restating any reference code, the name
+``S_hat`` is injected into that module's globals (bound to ``model.S_hat``) before each
+step; the fixture records ``sparsegap_patch='module-global S_hat = model.S_hat'``.
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get('ORIANA_REFERENCE', '/root/reference')
+
+
+def import_reference():
+    np.float = float      # shim 1
+    np.int = int
+    nb = types.ModuleType('numba')  # shim 2
+
+    def jit(*a, **k):
+        def deco(f):
+            return f
+        return deco
+    nb.jit = jit
+    sys.modules['numba'] = nb
+    sys.path.insert(0, REF)
+    import oriana  # noqa: F401
+    import oriana.models
+    import oriana.models.sparse_gap
+    import oriana.singlecell
+    import oriana.utils
+    return oriana
+
+
+PARAM_KEYS = ['alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_d', 'p_d', 'pi_s', 'p_s']
+ARRAY_KEYS = {'U_hat': 'U_hat', 'V_hat': 'V_hat', 'Vprime_hat': 'V_hat', 'log_U_hat': 'log_U_hat',
+              'log_V_hat': 'log_V_hat', 'log_Vprime_hat': 'log_V_hat', 'S_hat': 'S_hat'}
+
+
+def snapshot(model, tag, out):
+    for key in PARAM_KEYS:
+        if hasattr(model, key):
+            out['%s/%s' % (tag, key)] = np.array(getattr(model, key)[:])
+    for key, name in ARRAY_KEYS.items():
+        if hasattr(model, key):
+            out['%s/%s' % (tag, name)] = np.array(getattr(model, key))
+
+
+def kernel_io(oriana, name, model, out):
+    """One raw call of the model's compute_Z_q_expectations on the post-init state."""
+    n, m, K = model.n, model.m, model.k
+    X = model.X[:].astype(np.float32)
+    Zi = np.empty((n, K), dtype=np.float32)
+    Zj = np.empty((m, K), dtype=np.float32)
+    Zl = np.empty((m, K), dtype=np.float32)
+    M = oriana.models
+    if name == 'GaP':
+        M.GaP.compute_Z_q_expectations(Zi, Zj, model.log_U_hat, model.log_V_hat, X)
+        Zl[:] = 0
+    elif name == 'ZIGaP':
+        M.ZIGaP.compute_Z_q_expectations(Zi, Zj, Zl, model.log_U_hat, model.log_V_hat, model.D_hat, X)
+    elif name == 'SparseGaP':
+        St = (model.p_s[:] > model.tau).astype(np.float32)
+        M.SparseGaP.compute_Z_q_expectations(Zi, Zj, Zl, model.log_U_hat, model.log_Vprime_hat,
+                                             St, model.S_hat, X)
+    else:
+        St = (model.p_s[:] > model.tau).astype(np.float32)
+        M.SparseZIGaP.compute_Z_q_expectations(Zi, Zj, Zl, model.log_U_hat, model.log_Vprime_hat,
+                                               St, model.S_hat, model.D_hat, X)
+    out['kernel/Zi'] = Zi
+    out['kernel/Zj'] = Zj
+    out['kernel/Zlog'] = Zl
+
+
+def run_case(oriana, name, n, m, k, use_factors, seed, sweeps=(1, 2, 3, 10)):
+    from oriana.singlecell import CountMatrix, generate_factor_matrices
+    np.random.seed(seed)
+    X, _, _, _ = generate_factor_matrices(n, m, k)
+    np.random.seed(seed + 1)
+    cls = getattr(oriana.models, name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = cls(CountMatrix(np.asarray(X)), k=k, use_factors=use_factors)
+    out = {'X': np.asarray(X, dtype=np.int64),
+           'meta/name': np.array(name), 'meta/k': np.array(k), 'meta/use_factors': np.array(use_factors),
+           'meta/seed': np.array(seed), 'meta/tau': np.array(getattr(model, 'tau', 0.5)),
+           'meta/sparsegap_patch': np.array('module-global S_hat = model.S_hat' if name == 'SparseGaP' else ''),
+           # NMF warm start as left in the U / V node buffers by base.py:38-40 (an INPUT fixture:
+           # scikit-learn is unpinned, its output is not something to reproduce)
+           'nmf/U': np.array(model.U[:]), 'nmf/V': np.array(model.V[:])}
+    snapshot(model, 's0', out)
+    kernel_io(oriana, name, model, out)
+    done = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for target in sweeps:
+            while done < target:
+                if name == 'SparseGaP':
+                    oriana.models.sparse_gap.S_hat = model.S_hat
+                model.step()
+                done += 1
+            snapshot(model, 's%d' % target, out)
+    return out
+
+
+def tables(oriana):
+    from oriana.utils import digamma, inverse_digamma, sigmoid, logit
+    out = {}
+    with np.errstate(all='ignore'):
+        xs = np.asarray([-2.3, 1.5, 0.45, -0.78, 5.3, -.2, 0., -745., 745., -36., 36., 1e-15])   # test.py:14
+        out['sigmoid/x'] = xs
+        out['sigmoid/y'] = sigmoid(xs)
+        ps = np.asarray([0.45, 0.001, 0.9987, 0.63, 0.745, 0.521, 0.32, 0., 1., 1e-15, 1e-16, 1. - 1e-10, 1e-10])  # test.py:19
+        out['logit/x'] = ps
+        out['logit/y'] = logit(ps)
+        gs = np.asarray([0.54, 6.2, 1.2, 0.3, 7.9, 4.5, 2.1, 1e-15, 1e-8, 1e-3, 1., 1.4616321449683623,
+                         10., 1e3, 1e6, 3.7e8])                                                     # test.py:24
+        out['digamma/x'] = gs
+        out['digamma/y'] = digamma(gs)
+        out['digamma/y32'] = digamma(gs.astype(np.float32))
+        ys = np.concatenate([digamma(gs), np.asarray([0.54, 6.2, 1.2, 0.3, 7.9, 4.5, 2.1, -2.22, -2.2200001,
+                                                     -5., -50., -1e3, -1e15, 0., 13.8, 20.])])
+        out['inverse_digamma/x'] = ys
+        out['inverse_digamma/y'] = inverse_digamma(ys)
+    return out
+
+
+def main():
+    oriana = import_reference()
+    np.savez_compressed(os.path.join(HERE, 'tables.npz'), **tables(oriana))
+    shapes = {'c1': (200, 80, 5, 0), 'odd': (257, 131, 7, 100)}
+    for name in ('GaP', 'ZIGaP', 'SparseGaP', 'SparseZIGaP'):
+        for tag, (n, m, k, seed) in shapes.items():
+            for uf in (False, True):
+                out = run_case(oriana, name, n, m, k, uf, seed + (10 if uf else 0))
+                fn = '%s_%s_%s.npz' % (name.lower(), tag, 'nmf' if uf else 'rand')
+                np.savez_compressed(os.path.join(HERE, fn), **out)
+                print('wrote', fn, 'zeros=%.3f' % (out['X'] == 0).mean())
+
+
+if __name__ == '__main__':
+    main()

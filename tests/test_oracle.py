@@ -1,0 +1,116 @@
+# -*- coding: utf-8 -*-
+"""Pins oracle/ (the CPU restatement) against golden vectors captured from the reference
+itself (tests/golden/make_golden.py) and the known answers of the reference's own unit
+tests (reference test/test.py:13-79).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden_files, load_golden, state_of, assert_state_close, err_colrel
+from oracle import cavi_oracle as co
+
+
+def _model(g):
+    name = str(g['meta/name'])
+    return co.MODELS[name](g['X'], int(g['meta/k']), g['s0/a1'], g['s0/b1'], tau=float(g['meta/tau']))
+
+
+@pytest.mark.parametrize('path', golden_files(), ids=os.path.basename)
+def test_init_state_exact(path):
+    """Post-constructor state (expectations + first M-step) is bit-identical."""
+    g = load_golden(path)
+    got = _model(g).state()
+    ref = state_of(g, 's0')
+    for k, v in ref.items():
+        if k in got:
+            assert np.array_equal(got[k], v), k
+
+
+@pytest.mark.parametrize('path', golden_files(), ids=os.path.basename)
+def test_kernel_io(path):
+    """Raw loop-nest outputs on the post-init inputs.  glibc expf vs
+    NumPy's SIMD exp differ by <= 1 ulp, hence 1e-6 and not bit equality."""
+    g = load_golden(path)
+    M = _model(g)
+    M.update_variational_parameters()
+    Zi, Zj, Zlog = M.last_Z
+    assert err_colrel(Zi, g['kernel/Zi']) < 1e-6
+    assert err_colrel(Zj, g['kernel/Zj']) < 1e-6
+    if M.zi or M.sparse:
+        assert err_colrel(Zlog, g['kernel/Zlog']) < 1e-6
+
+
+@pytest.mark.parametrize('path', golden_files(), ids=os.path.basename)
+def test_single_sweeps(path):
+    """Each sweep, started from the reference's own state, lands on the reference's next state."""
+    g = load_golden(path)
+    for a, b in (('s0', 's1'), ('s1', 's2'), ('s2', 's3')):
+        M = _model(g)
+        M.load_state(state_of(g, a))
+        if M.zi:
+            M.D_hat = M.p_d.astype(np.float32)
+        M.step()
+        assert_state_close(M.state(), state_of(g, b), what='%s->%s' % (a, b))
+
+
+@pytest.mark.parametrize('path', golden_files('gap_*rand.npz') + golden_files('zigap_c1_rand.npz'),
+                         ids=os.path.basename)
+def test_trajectory(path):
+    """Ten free-running sweeps stay close (errors compound, so the bound is loose)."""
+    g = load_golden(path)
+    M = _model(g)
+    for _ in range(10):
+        M.step()
+    assert_state_close(M.state(), state_of(g, 's10'), rtol=2e-3, what='s10')
+
+
+def test_tables(golden_dir):
+    t = np.load(os.path.join(golden_dir, 'tables.npz'))
+    with np.errstate(all='ignore'):
+        assert np.array_equal(co.sigmoid(t['sigmoid/x']), t['sigmoid/y'])
+        assert np.array_equal(co.logit(t['logit/x']), t['logit/y'])
+        assert np.array_equal(co.digamma(t['digamma/x']), t['digamma/y'])
+        np.testing.assert_array_equal(co.inverse_digamma(t['inverse_digamma/x']), t['inverse_digamma/y'])
+
+
+# ---- known answers of the reference's own tests (test/test.py) ----
+def test_ref_sigmoid_logit_roundtrip():        # test/test.py:13-20
+    x = np.asarray([-2.3, 1.5, 0.45, -0.78, 5.3, -.2, 0.])
+    np.testing.assert_almost_equal(co.logit(co.sigmoid(x)), x)
+    p = np.asarray([0.45, 0.001, 0.9987, 0.63, 0.745, 0.521, 0.32])
+    np.testing.assert_almost_equal(co.sigmoid(co.logit(p)), p)
+
+
+def test_ref_digamma_roundtrip():              # test/test.py:23-32
+    x = np.asarray([0.54, 6.2, 1.2, 0.3, 7.9, 4.5, 2.1])
+    np.testing.assert_almost_equal(co.inverse_digamma(co.digamma(x)), x)
+    np.testing.assert_almost_equal(co.digamma(co.inverse_digamma(x)), x)
+
+
+def test_ref_gamma_bernoulli_means():          # test/test.py:35-41, 60-79 ('d,d' layout)
+    a = np.asarray([[2.1, 1.8], [0.7, 2.3]])
+    np.testing.assert_almost_equal(co.gamma_mean(a, np.ones((2, 2))), a)
+    np.testing.assert_almost_equal(co.gamma_meanlog(a, np.ones((2, 2))), co.digamma(a))
+    p = np.asarray([[0.02, 0.34], [0.62, 0.79]])
+    np.testing.assert_almost_equal(co.bernoulli_mean(p), p)
+
+
+def test_kernel_rejects_wrong_dtype():
+    """numba's explicit signature raises TypeError on dtype mismatch (gap.py:67)."""
+    z = np.zeros((2, 2), dtype=np.float32)
+    with pytest.raises(TypeError):
+        co.zq_gap(z, z.copy(), z.astype(np.float64), z, z)
+
+
+def test_empty_and_zero_inputs():
+    K = 3
+    lu = np.zeros((4, K), np.float32)
+    lv = np.zeros((5, K), np.float32)
+    Zi = np.empty((4, K), np.float32)
+    Zj = np.empty((5, K), np.float32)
+    co.zq_gap(Zi, Zj, lu, lv, np.zeros((4, 5), np.float32))
+    assert not Zi.any() and not Zj.any()
+    # den == 0 guard (gap.py:76): all exponentials underflow -> contributions are 0, not NaN
+    co.zq_gap(Zi, Zj, lu - 1e15, lv, np.ones((4, 5), np.float32))
+    assert not Zi.any() and not Zj.any()

@@ -1,0 +1,189 @@
+/*
+ * oriana_hip.h -- C ABI of the MI355X (gfx950) CAVI engine for probabilistic count matrix
+ * factorisation.  This is the drop-in boundary for the hot path of AntoinePassemiers/Oriana:
+ * every entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  Plain pointers and sizes only; all pointers are DEVICE pointers unless a
+ * parameter is documented as host.  Calls are asynchronous on `stream` (a hipStream_t passed as
+ * void*; NULL = the default stream).  Return value: 0 on success, a negative code otherwise
+ * (-1000 - hipError_t for HIP errors, ORIANA_E* for argument errors); nothing is thrown.
+ * The library keeps no global state; all scratch memory is supplied by the caller.
+ *
+ * Layouts
+ *   - "dense (r, K) f32/f64": C-contiguous, exactly the reference's ndarray layout
+ *     (oriana/parameters.py:8-32 holds float64 buffers; the kernels take float32, gap.py:67).
+ *   - "factor matrix (r, Kp) f32": K padded with zeros to Kp = oriana_kpad(K); row-major.
+ *   - oriana_counts: the count matrix X (constant across sweeps, oriana/models/gap.py:29-32)
+ *     repacked once into 256 x 256 tiles that keep only the non-zero counts; see DESIGN.md.
+ */
+#ifndef ORIANA_HIP_H
+#define ORIANA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORIANA_TILE 256
+
+#define ORIANA_EINVAL   (-1)   /* bad argument (NULL pointer, negative size, K out of range) */
+#define ORIANA_EKRANGE  (-2)   /* K larger than the largest compiled configuration */
+#define ORIANA_EQUIRK   (-3)   /* reference_quirks needs K <= m (zigap.py:94 reads D_hat[i, k]) */
+
+/* 8-byte record of one non-zero count, row-major inside its tile. */
+typedef struct {
+    float    x;     /* the count, as float32 (gap.py:94 casts X to float32) */
+    uint16_t cpos;  /* position of this entry in the tile's column-major order */
+    uint8_t  col;   /* column inside the tile */
+    uint8_t  pad;
+} oriana_rowrec;
+
+/* Tiled non-zero layout of one row shard of X.  All arrays live in device memory and are owned
+ * by the caller (the Python host allocates them as torch tensors). */
+typedef struct {
+    int64_t n, m;                 /* rows (cells) in this shard, columns (genes) */
+    int64_t nrb, ncb;             /* ceil(n / 256), ceil(m / 256) */
+    int64_t nnz;                  /* non-zero entries */
+    const int64_t       *tile_off;   /* [nrb*ncb + 1] first entry of tile (rb, cb), rb-major */
+    const uint32_t      *row_ptr;    /* [nrb*ncb][257] row starts inside the tile */
+    const uint32_t      *col_ptr;    /* [nrb*ncb][257] column starts inside the tile */
+    const oriana_rowrec *rowrec;     /* [nnz] row-major records */
+    const uint8_t       *ridx;       /* [nnz] row inside the tile, column-major order */
+} oriana_counts;
+
+/* Kp for a given K (0 if K is out of range). */
+int64_t oriana_kpad(int64_t K);
+/* Library / build identification ("oriana_hip gfx950 <version>"). */
+const char *oriana_version(void);
+
+/* ---- packing the count matrix (replaces `self.X[:].astype(np.float32)`, gap.py:94) --------
+ * Two passes over dense row chunks (a chunk starts at a multiple of 256 rows):
+ *   1. oriana_pack_count   -> per-tile nnz + per-tile row / column counts
+ *   2. (caller) exclusive scan of tile_cnt -> tile_off
+ *   3. oriana_pack_fill    -> rowrec / ridx / row_ptr / col_ptr
+ * X is dense (rows, m) with leading dimension ldx (elements), float32 or (xdtype = 1) int64 /
+ * (xdtype = 2) int32 / (xdtype = 3) float64.  rb0 = first row block of the chunk.
+ */
+int oriana_pack_count(const void *X, int xdtype, int64_t rows, int64_t m, int64_t ldx,
+                      int64_t rb0, int64_t ncb,
+                      int32_t *tile_cnt,      /* [nrb*ncb] */
+                      uint32_t *row_ptr,      /* [nrb*ncb][257]: receives per-row counts */
+                      uint32_t *col_ptr,      /* [nrb*ncb][257]: receives per-column counts */
+                      void *stream);
+int oriana_pack_fill(const void *X, int xdtype, int64_t rows, int64_t m, int64_t ldx,
+                     int64_t rb0, int64_t ncb, const int64_t *tile_off,
+                     uint32_t *row_ptr, uint32_t *col_ptr,   /* counts in, offsets out */
+                     oriana_rowrec *rowrec, uint8_t *ridx,
+                     /* optional: gather a dense (rows, m) f32 side matrix (D_hat) at the non-zeros */
+                     const float *side, int64_t ldside, float *side_nz,
+                     void *stream);
+
+/* ---- factor preparation ---------------------------------------------------------------------
+ * From E[log U] (gamma.py:52-61 output, dense (r, K) f32) build the factor matrix
+ *   F[i, k] = exp(l[i, k] - mu[i]) * (mask ? mask[i, k] : 1),   mu[i] = max_k l[i, k],
+ * the shift being undone analytically (softmax is shift invariant, gap.py:74-78).  Rows whose
+ * shift is too large for the shifted form to reproduce the reference's float32 behaviour are
+ * filled with NaN: every entry that touches them is evaluated by the exact slow path.
+ */
+int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask,
+                       int64_t r, int64_t K, void *stream);
+
+/* ---- the responsibility pass ----------------------------------------------------------------
+ * Replaces the loop nests  GaP.compute_Z_q_expectations        (oriana/models/gap.py:67-80)
+ *                          ZIGaP.compute_Z_q_expectations      (oriana/models/zigap.py:79-95)
+ *                          SparseGaP.compute_Z_q_expectations  (oriana/models/sparse_gap.py:81-97)
+ *                          SparseZIGaP.compute_Z_q_expectations(oriana/models/sparse_zigap.py:100-116)
+ * in three kernels over the tiled non-zeros:
+ *   oriana_row_pass : s_ij = x_ij / sum_k FU[i,k] FVden[j,k]   and   R[i,:] = sum_j w_ij s_ij FVacc[j,:]
+ *   oriana_col_pass : C[j,:] (+)= sum_i s_ij G[i,:]
+ *   oriana_fixup    : entries the shifted form cannot represent (NaN sentinel in s) are evaluated
+ *                     exactly as the reference does (expf of the sum, den > 0 guard) and added
+ *                     with atomics to the dense outputs.
+ */
+int oriana_row_pass(const oriana_counts *cm,
+                    const float *FU,        /* (n, Kp) */
+                    const float *FVden,     /* (m, Kp) */
+                    const float *FVacc,     /* (m, Kp) or NULL = FVden */
+                    const float *w_nz,      /* [nnz] per-entry weight (D_hat at the non-zeros) or NULL = 1 */
+                    float *R,               /* (n, Kp) out */
+                    float *s_col,           /* [nnz] out: s_ij (unweighted), column-major tile order */
+                    float *sw_col,          /* [nnz] out: w_ij s_ij, or NULL */
+                    float *s_row,           /* [nnz] out: s_ij row-major, or NULL */
+                    int32_t *tile_flag,     /* [nrb*ncb] out: 1 if the tile holds slow-path entries */
+                    int64_t K, void *stream);
+
+int oriana_row_spmm(const oriana_counts *cm, const float *s_row, const float *w_nz,
+                    const float *FV, float *R, int64_t K, void *stream);
+
+int oriana_col_pass(const oriana_counts *cm, const float *s_col,
+                    const float *G,         /* (n, Kp) */
+                    float *C,               /* (m, Kp) accumulated with atomics: zero it first */
+                    int64_t K, void *stream);
+
+/* Z[i,k] = (zero_first ? 0 : Z[i,k]) + F[i,k] * R[i,k] (* mul[i,k] if mul)  -- dense (r, K) out. */
+int oriana_finalize(float *Z, const float *F, const float *R, const float *mul,
+                    int64_t r, int64_t K, int accumulate, void *stream);
+
+/* Slow path (exact reference arithmetic) for the entries flagged by oriana_row_pass.
+ * variant bit 0: S_tilde / S_hat present (sparse models); bit 1: D_hat weights (w_nz);
+ * bit 2: reference quirk zigap.py:94 (dq = D_hat[:, :K] dense (n, K)).
+ * Adds into Zi (n, K), Zj (m, K), Zlog (m, K) (any may be NULL) and rewrites the sentinels in
+ * s_col / sw_col / s_row as 0. */
+int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag,
+                 float *s_col, float *sw_col, float *s_row,
+                 const float *logU, const float *logV,
+                 const float *S_tilde, const float *S_hat,
+                 const float *w_nz, const float *dq,
+                 float *Zi, float *Zj, float *Zlog,
+                 int64_t K, int variant, void *stream);
+
+/* ---- stateless drop-ins with the reference's exact signatures (outputs first) ------------------
+ * X dense (n, m) f32.  `ws` is caller-provided scratch of at least oriana_zq_workspace_bytes()
+ * bytes (256-byte aligned); these entry points pack X on every call, as the reference re-casts X
+ * on every call (gap.py:94).  The model classes use the resident oriana_counts instead.
+ */
+int64_t oriana_zq_workspace_bytes(int64_t n, int64_t m, int64_t K, int64_t nnz_bound);
+int oriana_zq_gap_f32(float *Z_hat_i, float *Z_hat_j,
+                      const float *log_U_hat, const float *log_V_hat, const float *X,
+                      int64_t n, int64_t m, int64_t K, void *ws, int64_t ws_bytes, void *stream);
+
+/* ---- Gamma / Bernoulli updates and the M-step --------------------------------------------------
+ * oriana_gamma_update: one side (U or V) of update_variational_parameters
+ *   (gap.py:96-110, zigap.py:114-128, sparse_gap.py:117-132, sparse_zigap.py:137-152) fused with
+ *   Gamma.mean / Gamma.meanlog (nodes/probabilistic/gamma.py:37-61):
+ *     a1 = max(1e-15, nan_to_num(prior1[k] + zmul[i,k] * Z[i,k]))
+ *     a2 = max(1e-15, nan_to_num(prior2[k] + rmul[i,k] * (rate_mat ? rate_mat[i,k] : rate_vec[k])))
+ *     E = a1 / a2 (f64);  Elog = f32(digamma(f32(a1))) - logf(f32(a2))
+ *   and the column sums sum_i E[i,k], sum_i Elog[i,k] (f64, ADDED into colsum_E / colsum_Elog:
+ *   zero them first; they feed the M-step means, gap.py:120-122, and the other side's rate).
+ *   Z may be NULL (initialisation: a1/a2 are taken as they are, only expectations are produced).
+ */
+int oriana_gamma_update(double *a1, double *a2, double *E, float *Elog,
+                        double *colsum_E, double *colsum_Elog,
+                        const double *prior1, const double *prior2,
+                        const float *Z, const float *zmul,
+                        const double *rate_vec, const double *rate_mat, const float *rmul,
+                        int64_t r, int64_t K, void *stream);
+
+/* M-step for one Gamma node (gap.py:117-129; utils.py:39-51):
+ *   p1 = max(1e-15, nan_to_num(inverse_digamma(log(p2) + f32(colsum_Elog / count))))
+ *   p2 = max(1e-15, nan_to_num(p1 / (colsum_E / count)))            (K-vectors, f64, in place) */
+int oriana_mstep_gamma(double *p1, double *p2, const double *colsum_E, const double *colsum_Elog,
+                       double count, int64_t K, void *stream);
+
+/* Column sums of a dense (r, K) f64 matrix, optionally times an f32 (r, K) multiplier, added
+ * into out[K] (zero it first) -- `V_hat.sum(axis=0)`, gap.py:98. */
+int oriana_colsum_f64(double *out, const double *A, const float *mul, int64_t r, int64_t K, void *stream);
+
+/* Element-wise special functions on f64 vectors (oriana/utils.py:9-15, 31-51) -- used by tests
+ * and by the host mirror of oriana.utils. */
+int oriana_digamma_f64(double *y, const double *x, int64_t len, void *stream);
+int oriana_trigamma_f64(double *y, const double *x, int64_t len, void *stream);
+int oriana_inverse_digamma_f64(double *y, const double *x, int64_t len, void *stream);
+int oriana_sigmoid_f64(double *y, const double *x, int64_t len, void *stream);
+int oriana_logit_f64(double *y, const double *x, int64_t len, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORIANA_HIP_H */

@@ -1,0 +1,63 @@
+# -*- coding: utf-8 -*-
+"""Builds the gfx950 shared library IN-TREE (oriana_amd/csrc/liboriana_hip.so) with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels to the GPU box with the working tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'stateless.hip']
+LIB = os.path.join(CSRC, 'liboriana_hip.so')
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps += [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'oriana_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip source for gfx950 and link liboriana_hip.so.  Returns the path."""
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(CSRC, s.replace('.hip', '.o'))
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall',
+               '-Wno-unused-function', '-c', src, '-o', obj]
+        if verbose:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if verbose or p.returncode != 0:
+            sys.stderr.write(out.decode(errors='replace'))
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))

@@ -1,0 +1,94 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of the C ABI declared in include/oriana_hip.h.
+
+The HIP library is the product path: if it cannot be loaded this module raises -- there is no
+CPU fallback (the CPU restatement under oracle/ is test infrastructure only).
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_void_p, c_double, c_char_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'liboriana_hip.so')
+
+
+class OrianaHipError(RuntimeError):
+    pass
+
+
+class OrianaCounts(ctypes.Structure):
+    """struct oriana_counts (include/oriana_hip.h)."""
+    _fields_ = [('n', c_int64), ('m', c_int64), ('nrb', c_int64), ('ncb', c_int64), ('nnz', c_int64),
+                ('tile_off', c_void_p), ('row_ptr', c_void_p), ('col_ptr', c_void_p),
+                ('rowrec', c_void_p), ('ridx', c_void_p)]
+
+
+_P = c_void_p
+_I = c_int64
+_SIGS = {
+    'oriana_kpad': (c_int64, [_I]),
+    'oriana_version': (c_char_p, []),
+    'oriana_pack_count': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'oriana_pack_fill': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'oriana_factor_prep': (c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    'oriana_row_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
+    'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P]),
+    'oriana_finalize': (c_int, [_P, _P, _P, _P, _I, _I, c_int, _P]),
+    'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                             _I, c_int, _P]),
+    'oriana_gamma_update': (c_int, [_P] * 13 + [_I, _I, _P]),
+    'oriana_mstep_gamma': (c_int, [_P, _P, _P, _P, c_double, _I, _P]),
+    'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),
+    'oriana_digamma_f64': (c_int, [_P, _P, _I, _P]),
+    'oriana_trigamma_f64': (c_int, [_P, _P, _I, _P]),
+    'oriana_inverse_digamma_f64': (c_int, [_P, _P, _I, _P]),
+    'oriana_sigmoid_f64': (c_int, [_P, _P, _I, _P]),
+    'oriana_logit_f64': (c_int, [_P, _P, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liboriana_hip.so (building it is __graft_entry__.build()'s job).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OrianaHipError(
+                'HIP library %s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            if not hasattr(lib, name):
+                continue              # symbol table is checked separately (tests/test_abi.py)
+            f = getattr(lib, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an int-returning entry point; non-zero return -> OrianaHipError."""
+    f = getattr(load(), name)
+    rc = f(*args)
+    if rc != 0:
+        raise OrianaHipError('%s failed with code %d' % (name, rc))
+    return rc

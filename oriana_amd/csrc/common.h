@@ -1,0 +1,141 @@
+// common.h -- device helpers shared by the gfx950 kernels of the CAVI engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+#include "../../include/oriana_hip.h"
+
+#define ORIANA_HIP_CHECK(expr)                                     \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return -1000 - (int)_e;              \
+    } while (0)
+
+#define ORIANA_LAUNCH_CHECK()                                      \
+    do {                                                           \
+        hipError_t _e = hipGetLastError();                         \
+        if (_e != hipSuccess) return -1000 - (int)_e;              \
+    } while (0)
+
+namespace oriana {
+
+constexpr int TILE = ORIANA_TILE;          // 256 x 256 count tiles
+constexpr float DEN_MIN = 1e-10f;          // below this the shifted softmax denominator is not trusted
+constexpr float SHIFT_MAX = 22.0f;         // |row shift| above this -> exact slow path for the row
+
+// ---- DPP cross-lane moves (wave64; no LDS traffic) ------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// broadcast lane U of every quad to the whole quad
+template <int U>
+__device__ __forceinline__ uint32_t quad_bcast_u32(uint32_t v) { return dpp_u32<U * 0x55>(v); }
+template <int U>
+__device__ __forceinline__ float quad_bcast_f32(float v) { return dpp_f32<U * 0x55>(v); }
+
+// sum over aligned groups of G lanes (G = 4, 8, 16); every lane of the group gets the total
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]
+    if (G >= 8)  v += dpp_f32<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
+    if (G >= 16) v += dpp_f32<0x140>(v);   // row_mirror: lane i <-> 15 - i
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- special functions, float64 (scipy.special.digamma / polygamma(1, .) restated) ------------
+// digamma for x > 0: upward recurrence to x >= 10, then the asymptotic series.
+__device__ __forceinline__ double digamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double z = 1.0 / (x * x);
+    const double y = z * (1.0 / 12.0 - z * (1.0 / 120.0 - z * (1.0 / 252.0 - z * (1.0 / 240.0 -
+                     z * (1.0 / 132.0 - z * (691.0 / 32760.0 - z * (1.0 / 12.0)))))));
+    return r + log(x) - 0.5 / x - y;
+}
+
+__device__ inline double digamma_f64(double x) {
+    if (x != x) return x;
+    if (x == INFINITY) return x;
+    if (x == -INFINITY) return NAN;
+    if (x == 0.0) return copysign(INFINITY, -x);
+    if (x < 0.0) {
+        if (x == floor(x)) return NAN;
+        // reflection: psi(x) = psi(1 - x) - pi / tan(pi x)
+        double fr = x - floor(x);
+        return digamma_pos(1.0 - x) - M_PI / tan(M_PI * fr);
+    }
+    return digamma_pos(x);
+}
+
+__device__ __forceinline__ double trigamma_pos(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r += 1.0 / (x * x); x += 1.0; }
+    const double ix = 1.0 / x;
+    const double z = ix * ix;
+    // 1/x + 1/(2x^2) + sum B_2k / x^(2k+1)
+    const double s = z * ix * (1.0 / 6.0 - z * (1.0 / 30.0 - z * (1.0 / 42.0 - z * (1.0 / 30.0 -
+                     z * (5.0 / 66.0 - z * (691.0 / 2730.0 - z * (7.0 / 6.0)))))));
+    return r + ix + 0.5 * z + s;
+}
+
+__device__ inline double trigamma_f64(double x) {
+    if (x != x) return x;
+    if (x == INFINITY) return 0.0;
+    if (x == -INFINITY) return NAN;
+    if (x <= 0.0) {
+        if (x == floor(x)) return INFINITY;
+        double fr = x - floor(x);
+        double sn = sin(M_PI * fr);
+        return (M_PI * M_PI) / (sn * sn) - trigamma_pos(1.0 - x);
+    }
+    return trigamma_pos(x);
+}
+
+// oriana/utils.py:39-51
+__device__ inline double inverse_digamma_f64(double y) {
+    const double psi1 = -0.5772156649015329;   // digamma(1)
+    double x = (y >= -2.22) ? exp(y) + 0.5 : -1.0 / (y - psi1);
+    #pragma unroll 1
+    for (int it = 0; it < 5; ++it) x -= (digamma_f64(x) - y) / trigamma_f64(x);
+    return x;
+}
+
+// np.nan_to_num followed by np.maximum(1e-15, .)  (gap.py:99-100)
+__device__ __forceinline__ double nan_to_num(double v) {
+    if (v != v) return 0.0;
+    if (v == INFINITY) return DBL_MAX;
+    if (v == -INFINITY) return -DBL_MAX;
+    return v;
+}
+__device__ __forceinline__ double clamp_eps(double v) { return fmax(1e-15, nan_to_num(v)); }
+
+// oriana/utils.py:9-15
+__device__ __forceinline__ double sigmoid_f64(double x) { return 1.0 / (1.0 + exp(-x)); }
+__device__ __forceinline__ double logit_f64(double x) {
+    if (x == x) x = fmin(fmax(x, 1e-15), 1.0 - 1e-15);   // np.clip keeps NaN
+    return log(x / (1.0 - x));
+}
+
+// Gamma.meanlog (nodes/probabilistic/gamma.py:52-61): parameters cast to f32 first, SciPy's f32
+// digamma is the f64 one rounded to f32, then an f32 log and an f32 subtraction.
+__device__ __forceinline__ float gamma_meanlog_f32(double a1, double a2) {
+    const float a1f = (float)a1;
+    const float a2f = (float)a2;
+    const float psi = (float)digamma_f64((double)a1f);
+    const float lg = (float)log((double)a2f);
+    return psi - lg;
+}
+
+}  // namespace oriana

@@ -1,0 +1,149 @@
+# -*- coding: utf-8 -*-
+"""Parity of the HIP responsibility pass (through the C ABI) with the CPU oracle.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_files, load_golden, err_colrel
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # north_star tolerance; the sums are float32 on both sides
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from oriana_amd import engine
+    assert torch.cuda.is_available()
+    return engine
+
+
+def _rand_counts(rng, n, m, density, maxv=50):
+    X = rng.poisson(3.0, size=(n, m)).astype(np.int64) + 1
+    X *= (rng.random((n, m)) < density)
+    X[rng.random((n, m)) < 0.01 * density] = maxv * 1000
+    return X
+
+
+@pytest.mark.parametrize('n,m,density,dtype', [(257, 131, 0.3, np.int64), (600, 700, 0.1, np.float32),
+                                               (256, 256, 1.0, np.int32), (1, 1, 1.0, np.float64),
+                                               (513, 5, 0.5, np.int64), (300, 300, 0.0, np.float32)])
+def test_pack_roundtrip(eng, n, m, density, dtype):
+    rng = np.random.default_rng(n * 1000 + m)
+    X = _rand_counts(rng, n, m, density).astype(dtype)
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    assert ct.nnz == int((X != 0).sum())
+    assert np.array_equal(ct.to_dense(), X.astype(np.float32))
+    # column-major structures: ridx / cpos consistent with the row-major records
+    if ct.nnz:
+        T = 256
+        off = ct.tile_off.cpu().numpy()
+        rp = ct.row_ptr.cpu().numpy().view(np.uint32).reshape(-1, T + 1)
+        cp = ct.col_ptr.cpu().numpy().view(np.uint32).reshape(-1, T + 1)
+        rec = ct.rowrec[:ct.nnz].cpu().numpy().view(np.dtype([('x', '<f4'), ('cpos', '<u2'), ('col', 'u1'), ('pad', 'u1')]))
+        ridx = ct.ridx[:ct.nnz].cpu().numpy()
+        for t in range(ct.nrb * ct.ncb):
+            cnt = off[t + 1] - off[t]
+            assert rp[t, T] == cnt and cp[t, T] == cnt
+            seen = np.zeros(cnt, dtype=bool)
+            for r in range(T):
+                for p in range(rp[t, r], rp[t, r + 1]):
+                    e = rec[off[t] + p]
+                    c = int(e['col']); q = int(e['cpos'])
+                    assert cp[t, c] <= q < cp[t, c + 1]
+                    assert ridx[off[t] + q] == r
+                    assert not seen[q]
+                    seen[q] = True
+            assert seen.all()
+
+
+def _same_zeros(got, ref):
+    """Where one side is exactly 0 the other is at most denormal dust (< 1e-30 of the column max):
+    the factorised exponentials underflow at slightly different points than exp(lu + lv)."""
+    thr = 1e-30 * np.maximum(np.abs(ref).max(axis=0, keepdims=True), 1e-30)
+    assert (np.abs(got)[ref == 0] <= np.broadcast_to(thr, ref.shape)[ref == 0]).all()
+    assert (np.abs(ref)[got == 0] <= np.broadcast_to(thr, ref.shape)[got == 0]).all()
+
+
+def _run_gap(eng, X, lu, lv):
+    from oracle import cavi_oracle as co
+    n, m = X.shape
+    K = lu.shape[1]
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    ws = eng.ZWorkspace(ct, K)
+    Zi = torch.empty(n, K, dtype=torch.float32, device='cuda')
+    Zj = torch.empty(m, K, dtype=torch.float32, device='cuda')
+    eng.zq_gap(ws, Zi, Zj, torch.from_numpy(lu).cuda(), torch.from_numpy(lv).cuda())
+    torch.cuda.synchronize()
+    rZi = np.empty((n, K), np.float32); rZj = np.empty((m, K), np.float32)
+    co.zq_gap(rZi, rZj, lu, lv, np.ascontiguousarray(X.astype(np.float32)))
+    return Zi.cpu().numpy(), Zj.cpu().numpy(), rZi, rZj, ws
+
+
+@pytest.mark.parametrize('path', golden_files('gap_*.npz'), ids=os.path.basename)
+def test_zq_gap_golden(eng, path):
+    """Against the REFERENCE's own kernel output (golden) and the oracle, on the post-init state."""
+    g = load_golden(path)
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, g['X'], g['s0/log_U_hat'], g['s0/log_V_hat'])
+    assert err_colrel(Zi, g['kernel/Zi']) < RTOL
+    assert err_colrel(Zj, g['kernel/Zj']) < RTOL
+    assert err_colrel(Zi, rZi) < RTOL
+    assert err_colrel(Zj, rZj) < RTOL
+    # zero patterns (den == 0 guard / exp underflow) must agree, up to float32 denormal dust
+    _same_zeros(Zi, g['kernel/Zi'])
+    _same_zeros(Zj, g['kernel/Zj'])
+
+
+@pytest.mark.parametrize('n,m,K,density', [(300, 270, 5, 0.3), (257, 131, 7, 0.5), (512, 300, 20, 0.1),
+                                          (400, 520, 50, 0.1), (300, 257, 64, 0.2), (700, 300, 100, 0.1),
+                                          (260, 300, 128, 0.1), (300, 260, 200, 0.05), (257, 258, 256, 0.05),
+                                          (1, 300, 3, 1.0), (300, 1, 3, 1.0)])
+def test_zq_gap_random(eng, n, m, K, density):
+    rng = np.random.default_rng(K * 7 + n)
+    X = _rand_counts(rng, n, m, density)
+    lu = (rng.normal(size=(n, K)) * 2.0).astype(np.float32)
+    lv = (rng.normal(size=(m, K)) * 2.0 + 1.0).astype(np.float32)
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X, lu, lv)
+    assert int(ws.tile_flag.sum().item()) == 0          # everything on the fast path
+    assert err_colrel(Zi, rZi) < RTOL
+    assert err_colrel(Zj, rZj) < RTOL
+    # size-independent property: responsibilities sum to the counts
+    np.testing.assert_allclose(Zi.sum(1), X.sum(1), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(Zj.sum(1), X.sum(0), rtol=2e-5, atol=1e-3)
+
+
+def test_zq_gap_slow_path(eng):
+    """Rows / columns outside the range the shifted form covers: exp underflow to denormals,
+    den == 0 guard (gap.py:76), huge shifts.  All must land on the reference's float32 answers."""
+    rng = np.random.default_rng(5)
+    n, m, K = 300, 280, 7
+    X = _rand_counts(rng, n, m, 0.3)
+    lu = rng.normal(size=(n, K)).astype(np.float32)
+    lv = rng.normal(size=(m, K)).astype(np.float32)
+    lu[3, :] = -1e15                      # digamma(1e-15): whole row underflows -> den == 0 guard
+    lu[7, :] -= 95.0                      # denormal exponentials, den > 0 but tiny
+    lu[11, :2] = -1e15                    # partially dead row (fast path: zeros in the factor)
+    lu[20, :] += 40.0                     # large shift -> slow path by |mu| test
+    lv[5, :] = -1e15
+    lv[9, :] -= 60.0
+    lv[13, :] += 30.0
+    lu[30, :] = np.float32(-80.0); lv[31, :] = np.float32(-30.0)
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X, lu, lv)
+    assert int(ws.tile_flag.sum().item()) > 0
+    assert np.isfinite(Zi).all() and np.isfinite(Zj).all()
+    assert err_colrel(Zi, rZi) < RTOL
+    assert err_colrel(Zj, rZj) < RTOL
+    assert not Zi[3].any() and not Zj[5].any()
+    _same_zeros(Zi, rZi)
+    _same_zeros(Zj, rZj)
+
+
+def test_zq_gap_rejects_wrong_dtype(eng):
+    X = np.ones((4, 4), np.int64)
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    ws = eng.ZWorkspace(ct, 2)
+    z = torch.zeros(4, 2, device='cuda')
+    with pytest.raises(TypeError):
+        eng.zq_gap(ws, z, z.clone(), z.double(), z.clone())

@@ -1,0 +1,2 @@
+from .base import *     # noqa: F401,F403
+from .gap import *      # noqa: F401,F403

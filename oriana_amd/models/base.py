@@ -1,0 +1,243 @@
+# -*- coding: utf-8 -*-
+"""Factor models: the reference's driver surface (constructor, ``step()``, ``factors()``, public
+attribute names -- reference oriana/models/base.py:13-130) over device-resident state and the HIP
+kernels of include/oriana_hip.h.  One process per GPU; cells (rows) are sharded across ranks.
+
+What is kept from the reference: attribute names and shapes (``alpha1 .. p_s`` are ``Parameter``
+objects holding float64 buffers, parameters.py:8-32), the order of the updates inside a sweep, the
+float32 / float64 split of every quantity, the clamps, and -- behind ``reference_quirks=True`` --
+the reference's index quirk (zigap.py:94).  What is not: the dense n x m rate matrix is never
+materialised (``UV`` is evaluated on demand), X is packed once instead of re-cast every sweep.
+"""
+import numpy as np
+import torch
+
+from .. import engine
+from .._lib import call, ptr, stream_ptr, OrianaHipError
+from ..parameters import Parameter
+from ..dims import Dimensions
+from .. import dist as odist
+
+__all__ = ['FactorModel']
+
+
+class _Buffer:
+    """Minimal stand-in for a reference node (``model.U[:]``, ``.buffer``, ``.asarray()``)."""
+
+    def __init__(self, getter):
+        self._getter = getter
+
+    @property
+    def buffer(self):
+        return self._getter()
+
+    def asarray(self):
+        return self._getter().detach().cpu().numpy()
+
+    def __getitem__(self, key):
+        return self._getter()[key].detach().cpu().numpy()
+
+
+class FactorModel:
+    """Base class (reference models/base.py:13-56).
+
+    Parameters
+    ----------
+    cmatrix : object with ``.shape`` and ``.as_array()`` (reference CountMatrix, base.py:22-23,
+        gap.py:31), a NumPy array, a torch tensor, or an ``engine.CountTiles`` already resident
+        on the device.  With a process group this is the LOCAL row shard.
+    k : number of factors.  use_factors : warm-start a1 / b1 from NMF factors (base.py:37-40).
+    init : optional ``(a1, b1)`` arrays (post-clamp initial shapes) -- bypasses NMF / host RNG.
+    device : torch device (default cuda).  process_group : torch.distributed group for row sharding.
+    reference_quirks : reproduce zigap.py:94 (``D_hat[i, k]``) -- see SURVEY.md 8(a) policy.
+    """
+
+    zi = False
+    sparse = False
+
+    def __init__(self, cmatrix, k=2, use_factors=True, tau=0.5, init=None, device=None, process_group=None,
+                 reference_quirks=True, n_total=None):
+        if not torch.cuda.is_available():
+            raise OrianaHipError('oriana_amd needs a ROCm GPU: the CAVI kernels are HIP only (no CPU fallback)')
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.cmatrix = cmatrix
+        self.k = int(k)
+        self.tau = tau
+        self.use_factors = use_factors
+        self.reference_quirks = reference_quirks
+        self.pg = process_group
+        self.world = odist.world_size(process_group)
+
+        X_host = None
+        if isinstance(cmatrix, engine.CountTiles):
+            self.counts = cmatrix
+        else:
+            X = cmatrix.as_array() if hasattr(cmatrix, 'as_array') else cmatrix
+            if not isinstance(X, torch.Tensor):
+                X = np.asarray(X)
+                X_host = X
+            self.counts = engine.CountTiles.from_dense(X, self.device)
+        self.n = self.counts.n
+        self.m = self.p = self.counts.m
+        self.n_total = int(n_total) if n_total is not None else odist.sum_int(self.n, process_group, self.device)
+        self.dims = Dimensions({'n': self.n, 'm': self.m, 'p': self.p, 'k': self.k})
+        if self.zi and self.reference_quirks and self.k > self.m:
+            raise ValueError('reference_quirks=True needs k <= number of genes (zigap.py:94 reads D_hat[i, k])')
+
+        K, n, m, dev = self.k, self.n, self.m, self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # prior hyper-parameters (build_u_node / build_v_node, gap.py:19-27): every value is
+        # overwritten by the first M-step except alpha2 = beta2 = 1, which that M-step reads
+        self.alpha1 = Parameter(torch.ones(K, **f64))
+        self.alpha2 = Parameter(torch.ones(K, **f64))
+        self.beta1 = Parameter(torch.ones(K, **f64))
+        self.beta2 = Parameter(torch.ones(K, **f64))
+        # variational parameters (define_variational_distribution, gap.py:34-44)
+        a1_0, b1_0, nmf = self._initial_shapes(X_host, init)
+        self.nmf_factors = nmf
+        self.a1 = Parameter(a1_0.to(**f64).clamp_(min=1e-15).contiguous())       # gap.py:55
+        self.a2 = Parameter(torch.ones(n, K, **f64))
+        self.b1 = Parameter(b1_0.to(**f64).clamp_(min=1e-15).contiguous())       # gap.py:65
+        self.b2 = Parameter(torch.ones(m, K, **f64))
+        # expectations (device); exposed as NumPy through the properties below
+        self._U_hat = torch.empty(n, K, **f64)
+        self._V_hat = torch.empty(m, K, **f64)
+        self._log_U_hat = torch.empty(n, K, **f32)
+        self._log_V_hat = torch.empty(m, K, **f32)
+        self._Zi = torch.empty(max(n, 1), K, **f32)
+        self._Zj = torch.empty(max(m, 1), K, **f32)
+        self._sumU = torch.zeros(2, K, **f64)        # [sum_i U_hat, sum_i log_U_hat]
+        self._sumV = torch.zeros(2, K, **f64)
+        self._ws = engine.ZWorkspace(self.counts, K, need_sw=False, need_srow=self.sparse)
+        self._init_extra()
+        self.U = _Buffer(lambda: self._U_hat)
+        self.V = _Buffer(lambda: self._effective_V())
+        self.UV = _Buffer(lambda: self._U_hat @ self._effective_V().t())          # lazy Einsum('nk,mk->nm')
+        self.n_sweeps = 0
+        self.initialize_parameters()
+
+    # ---- initial shapes -------------------------------------------------------------------------
+    def _initial_shapes(self, X_host, init):
+        """a1, b1 before the clamp.  With ``init`` given: exactly those.  Otherwise the reference's
+        host-side sequence is replayed (same np.random calls in the same order, then scikit-learn
+        NMF) so that ``np.random.seed(s)`` before the constructor gives the reference's start."""
+        if init is not None:
+            a1, b1 = init
+            return torch.as_tensor(np.asarray(a1, dtype=np.float64)), torch.as_tensor(np.asarray(b1, dtype=np.float64)), None
+        if X_host is None:
+            raise ValueError('init=(a1, b1) is required when the count matrix is already on the device')
+        if self.world > 1:
+            raise ValueError('init=(a1, b1) is required under row sharding (NMF sees the whole matrix)')
+        from .hostinit import reference_initial_shapes
+        a1, b1, nmf = reference_initial_shapes(type(self).__name__, X_host, self.k, self.use_factors)
+        return torch.from_numpy(a1), torch.from_numpy(b1), nmf
+
+    def _init_extra(self):
+        pass
+
+    def _effective_V(self):
+        return self._V_hat
+
+    # ---- reference surface ------------------------------------------------------------------------
+    def initialize_parameters(self):
+        """base.py:43-52: variational initialisation was done in __init__; expectations; M-step."""
+        self.update_expectations()
+        self.update_prior_hyper_parameters()
+
+    def step(self):
+        """One CAVI sweep (base.py:54-56)."""
+        self.update_variational_parameters()   # E-step
+        self.update_prior_hyper_parameters()   # M-step
+        self.n_sweeps += 1
+
+    def fit(self, n_iter=50):
+        """The loop user scripts write around step() (reference main.py:37-51)."""
+        for _ in range(int(n_iter)):
+            self.step()
+        return self
+
+    def factors(self):
+        """base.py:97-98: (U[:], V[:]) as host arrays."""
+        return self.U[:], self.V[:]
+
+    # expectations as host NumPy (the reference stores ndarrays in these attributes)
+    @property
+    def U_hat(self):
+        return self._U_hat.cpu().numpy()
+
+    @property
+    def V_hat(self):
+        return self._V_hat.cpu().numpy()
+
+    @property
+    def log_U_hat(self):
+        return self._log_U_hat.cpu().numpy()
+
+    @property
+    def log_V_hat(self):
+        return self._log_V_hat.cpu().numpy()
+
+    # ---- pieces shared by the four models ----------------------------------------------------------
+    def _gamma_side(self, side, Z, zmul=None, rate_vec=None, rate_mat=None, rmul=None, update=True):
+        """One side of update_variational_parameters + Gamma.mean / meanlog (oriana_gamma_update)."""
+        if side == 'u':
+            s1, s2, E, Elog, sums, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self._sumU, self.alpha1, self.alpha2, self.n
+        else:
+            s1, s2, E, Elog, sums, p1, p2, r = self.b1, self.b2, self._V_hat, self._log_V_hat, self._sumV, self.beta1, self.beta2, self.m
+        sums.zero_()
+        call('oriana_gamma_update', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
+             ptr(p1.tensor), ptr(p2.tensor), ptr(Z) if update else None, ptr(zmul), ptr(rate_vec), ptr(rate_mat),
+             ptr(rmul), r, self.k, stream_ptr())
+
+    def _mstep_side(self, side):
+        if side == 'u':
+            call('oriana_mstep_gamma', ptr(self.alpha1.tensor), ptr(self.alpha2.tensor), ptr(self._sumU[0]),
+                 ptr(self._sumU[1]), float(self.n_total), self.k, stream_ptr())
+        else:
+            call('oriana_mstep_gamma', ptr(self.beta1.tensor), ptr(self.beta2.tensor), ptr(self._sumV[0]),
+                 ptr(self._sumV[1]), float(self.m), self.k, stream_ptr())
+
+    def update_expectations(self):
+        """gap.py:131-135: expectations from the current a1, a2, b1, b2 (no parameter update)."""
+        self._gamma_side('u', None, update=False)
+        odist.all_reduce_sum(self._sumU, self.pg)
+        self._gamma_side('v', None, update=False)
+
+    def update_prior_hyper_parameters(self):
+        """gap.py:117-129."""
+        self._mstep_side('u')
+        self._mstep_side('v')
+
+    def update_variational_parameters(self):
+        raise NotImplementedError
+
+    # ---- state I/O (tests, checkpoints) ---------------------------------------------------------------
+    _PARAMS = ('alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_d', 'p_d', 'pi_s', 'p_s')
+
+    def state(self):
+        """Host copy of every parameter and expectation, keyed like the oracle / golden files."""
+        out = {}
+        for k in self._PARAMS:
+            if hasattr(self, k):
+                out[k] = getattr(self, k).asarray()
+        out.update(U_hat=self.U_hat, V_hat=self.V_hat, log_U_hat=self.log_U_hat, log_V_hat=self.log_V_hat)
+        return out
+
+    def load_state(self, st):
+        """Overwrite parameters (and recompute nothing): used to start a sweep from a given state."""
+        for k in self._PARAMS:
+            if k in st and hasattr(self, k):
+                getattr(self, k).tensor.copy_(torch.as_tensor(np.asarray(st[k], dtype=np.float64)).to(self.device))
+        for k, t in (('U_hat', self._U_hat), ('V_hat', self._V_hat), ('log_U_hat', self._log_U_hat),
+                     ('log_V_hat', self._log_V_hat)):
+            if k in st:
+                t.copy_(torch.as_tensor(np.asarray(st[k])).to(self.device, dtype=t.dtype))
+        # column sums that the next sweep reads
+        self._sumU[0] = self._U_hat.sum(0); self._sumU[1] = self._log_U_hat.double().sum(0)
+        odist.all_reduce_sum(self._sumU, self.pg)
+        self._sumV[0] = self._V_hat.sum(0); self._sumV[1] = self._log_V_hat.double().sum(0)
+        self._load_extra(st)
+
+    def _load_extra(self, st):
+        pass

@@ -1,0 +1,32 @@
+# -*- coding: utf-8 -*-
+"""pCMF = Gamma-Poisson factor model (reference oriana/models/gap.py:14-135)."""
+from .. import engine
+from .. import dist as odist
+from .base import FactorModel
+
+__all__ = ['GaP']
+
+
+class GaP(FactorModel):
+
+    @staticmethod
+    def compute_Z_q_expectations(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X, workspace=None):
+        """Drop-in for the reference's loop nest (gap.py:67-80): outputs first, caller allocates,
+        callee zero-fills, returns None.  All arguments are float32 device tensors; X is dense
+        (n, m) and is packed on every call (the model itself keeps X packed across sweeps)."""
+        ws = workspace
+        if ws is None:
+            ws = engine.ZWorkspace(engine.CountTiles.from_dense(X, X.device), log_U_hat.shape[1])
+        engine.zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat)
+
+    def update_variational_parameters(self):
+        """gap.py:82-115 (E-step)."""
+        # both Z sums use the PRE-update E[log U], E[log V] (one joint pass, gap.py:89-94)
+        engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat)
+        # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
+        self._gamma_side('u', self._Zi, rate_vec=self._sumV[0])
+        # the only cross-shard quantities of a sweep: the per-gene sums and the U_hat column sums
+        odist.all_reduce_sum(self._Zj, self.pg)
+        odist.all_reduce_sum(self._sumU, self.pg)
+        # V_q: b1 = beta1 + Z_j ; b2 = beta2 + sum_i U_hat (NEW U_hat)                   gap.py:105-110
+        self._gamma_side('v', self._Zj, rate_vec=self._sumU[0])

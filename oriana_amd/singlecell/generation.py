@@ -1,0 +1,81 @@
+# -*- coding: utf-8 -*-
+"""Synthetic count matrices, generated on the device one row chunk at a time.
+
+Row-blocked restatement of the reference generator (oriana/singlecell/generation.py:8-86):
+block-structured Gamma factors U (cells x k) and V (genes x k), per-gene expression probability
+pi_d ~ Beta(1, 1/z - 1), dropout mask D ~ Bernoulli(pi_d) and X = floor(D * U V^T) (no Poisson
+draw, generation.py:85-86).  Gamma(1, scale) is an exponential, so only uniform / exponential
+device RNG is needed.  The distribution is the reference's; the random streams are not (the
+reference draws from NumPy's global state on the host).
+
+A chunk is a pure function of (seed, row range): the tiled packer calls it twice (count, fill).
+"""
+import math
+
+import torch
+
+__all__ = ['SyntheticCounts']
+
+
+def _block_edges(total, n_groups):
+    step = total // n_groups
+    return [g * step for g in range(n_groups)] + [total]          # generation.py:9-12
+
+
+class SyntheticCounts:
+    """X = floor(D * U V^T) for cells [row0, row0 + n) of an (n_total, m) problem."""
+
+    def __init__(self, n_total, m, k, seed, device='cuda', zero_inflation_level=0.5, sparsity_degree_in_v=0.5,
+                 beta=80.0, theta=0.8, n_groups=2, row0=0, n=None):
+        self.n_total, self.m, self.k = int(n_total), int(m), int(k)
+        self.row0 = int(row0)
+        self.n = int(n) if n is not None else self.n_total - self.row0
+        self.seed = int(seed)
+        self.device = torch.device(device)
+        self.theta, self.n_groups = theta, n_groups
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.seed)                                  # replicated quantities: same on every rank
+        # generate_u (generation.py:8-37): per-group scale alpha / k, alpha in {100, 250}
+        choice = torch.randint(0, 2, (n_groups,), generator=g, device=self.device)
+        self.alpha = torch.where(choice == 0, 100.0, 250.0).to(torch.float32) / self.k
+        self.alpha_bar = float(self.alpha.mean().item())
+        self.u_row_edges = _block_edges(self.n_total, n_groups)
+        self.k_edges = _block_edges(self.k, n_groups)
+        # generate_v (generation.py:40-65)
+        m0 = int(round(self.m * sparsity_degree_in_v))
+        v_row_edges = _block_edges(m0, n_groups)
+        scale = torch.full((self.m, self.k), (1.0 - theta) * beta, dtype=torch.float32, device=self.device)
+        for grp in range(n_groups):
+            scale[v_row_edges[grp]:v_row_edges[grp + 1], self.k_edges[grp]:self.k_edges[grp + 1]] = beta
+        self.V = torch.empty(self.m, self.k, dtype=torch.float32, device=self.device).exponential_(1.0, generator=g) * scale
+        # pi_d ~ Beta(1, 1/z - 1) (generation.py:80): inverse CDF 1 - u^(1/b)
+        b = 1.0 / zero_inflation_level - 1.0
+        u = torch.rand(self.m, generator=g, device=self.device, dtype=torch.float64)
+        self.pi_d = (1.0 - u.pow(1.0 / b)).to(torch.float32) if b > 0 else torch.ones(self.m, device=self.device)
+
+    def _u_scale(self, r0, r1):
+        rows = torch.arange(self.row0 + r0, self.row0 + r1, device=self.device)
+        scale = torch.full((r1 - r0, self.k), (1.0 - self.theta) * self.alpha_bar, dtype=torch.float32, device=self.device)
+        for grp in range(self.n_groups):
+            inrow = (rows >= self.u_row_edges[grp]) & (rows < self.u_row_edges[grp + 1])
+            blk = scale[:, self.k_edges[grp]:self.k_edges[grp + 1]]
+            blk[inrow] = self.alpha[grp]
+        return scale
+
+    def chunk(self, r0, r1, dtype=torch.float32):
+        """Rows [r0, r1) of this shard as a dense device matrix (deterministic in (seed, rows))."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed((self.seed * 1000003 + (self.row0 + r0) * 7919 + 17) % (2 ** 62))
+        U = torch.empty(r1 - r0, self.k, dtype=torch.float32, device=self.device).exponential_(1.0, generator=g)
+        U *= self._u_scale(r0, r1)
+        lam = U @ self.V.t()
+        keep = torch.rand(r1 - r0, self.m, generator=g, device=self.device) < self.pi_d
+        x = torch.floor(lam) * keep
+        return x.to(dtype)
+
+    def labels(self, r0, r1):
+        rows = torch.arange(self.row0 + r0, self.row0 + r1, device=self.device)
+        lab = torch.zeros(r1 - r0, dtype=torch.int64, device=self.device)
+        for grp in range(self.n_groups):
+            lab[(rows >= self.u_row_edges[grp]) & (rows < self.u_row_edges[grp + 1])] = grp
+        return lab

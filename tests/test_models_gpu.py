@@ -1,0 +1,104 @@
+# -*- coding: utf-8 -*-
+"""Model-level parity on the GPU: each CAVI sweep of the HIP path (constructor / step() of the
+reference surface) against the golden states captured from the reference and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_files, load_golden, state_of, assert_state_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _cls(name):
+    import oriana_amd.models as M
+    return getattr(M, name, None)
+
+
+def _files():
+    import oriana_amd.models as M
+    return [f for f in golden_files() if hasattr(M, str(np.load(f)['meta/name']))]
+
+
+def _make(g, **kw):
+    cls = _cls(str(g['meta/name']))
+    return cls(g['X'], k=int(g['meta/k']), use_factors=bool(g['meta/use_factors']), tau=float(g['meta/tau']),
+               init=(g['s0/a1'], g['s0/b1']), **kw)
+
+
+@pytest.mark.parametrize('path', _files(), ids=os.path.basename)
+def test_init_state(path):
+    """Constructor = initialise + expectations + first M-step (base.py:43-52)."""
+    g = load_golden(path)
+    M = _make(g)
+    assert_state_close(M.state(), state_of(g, 's0'), what='init')
+
+
+@pytest.mark.parametrize('path', _files(), ids=os.path.basename)
+def test_seed_replay_matches_reference_start(path):
+    """np.random.seed(s); Model(X, k, use_factors) starts where the reference starts for that seed."""
+    g = load_golden(path)
+    np.random.seed(int(g['meta/seed']) + 1)
+    cls = _cls(str(g['meta/name']))
+    M = cls(g['X'], k=int(g['meta/k']), use_factors=bool(g['meta/use_factors']))
+    assert np.array_equal(M.a1.asarray(), g['s0/a1'])
+    assert np.array_equal(M.b1.asarray(), g['s0/b1'])
+    assert_state_close(M.state(), state_of(g, 's0'), what='seeded init')
+
+
+@pytest.mark.parametrize('path', _files(), ids=os.path.basename)
+def test_single_sweeps(path):
+    """Each sweep, started from the reference's own state, lands on the reference's next state
+    within 1e-5 (north_star) -- see helpers.KEY_RTOL for the Bernoulli posteriors."""
+    g = load_golden(path)
+    M = _make(g)
+    for a, b in (('s0', 's1'), ('s1', 's2'), ('s2', 's3')):
+        M.load_state(state_of(g, a))
+        M.step()
+        assert_state_close(M.state(), state_of(g, b), what='%s->%s' % (a, b))
+
+
+@pytest.mark.parametrize('path', [f for f in _files() if f.endswith('rand.npz')], ids=os.path.basename)
+def test_trajectory(path):
+    """Free-running sweeps (errors compound: loose bound), and fit() == repeated step()."""
+    g = load_golden(path)
+    M = _make(g)
+    M.fit(3)
+    assert_state_close(M.state(), state_of(g, 's3'), rtol=1e-3, what='s3 free-running')
+    M.fit(7)
+    assert M.n_sweeps == 10
+    assert_state_close(M.state(), state_of(g, 's10'), rtol=5e-3, what='s10 free-running')
+
+
+def test_factors_and_attributes():
+    g = load_golden(golden_files('gap_c1_rand.npz')[0])
+    M = _make(g)
+    M.step()
+    U, V = M.factors()
+    assert U.shape == (M.n, M.k) and V.shape == (M.m, M.k)
+    assert np.array_equal(U, M.U_hat) and np.array_equal(V, M.V_hat)
+    for name in ('alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2'):
+        p = getattr(M, name)
+        assert p.asarray().dtype == np.float64 and p[:].shape == p.shape
+    assert M.log_U_hat.dtype == np.float32 and M.U_hat.dtype == np.float64
+    assert M.UV[:].shape == (M.n, M.m)
+    assert M.p == M.m and M.dims['k'] == M.k
+
+
+def test_oracle_agreement_medium():
+    """A size the golden files do not cover (several tiles, K = 20): HIP sweep vs oracle sweep."""
+    from oracle import cavi_oracle as co
+    from oriana_amd.models import GaP
+    rng = np.random.default_rng(3)
+    n, m, K = 700, 600, 20
+    X = (rng.poisson(2.0, size=(n, m)) * (rng.random((n, m)) < 0.15)).astype(np.int64)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    M = GaP(X, k=K, init=(a1, b1))
+    O = co.OracleGaP(X, K, a1, b1)
+    assert_state_close(M.state(), O.state(), what='init')
+    for it in range(2):
+        O.load_state(M.state())
+        M.step(); O.step()
+        assert_state_close(M.state(), O.state(), what='sweep %d' % it)

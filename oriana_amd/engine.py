@@ -155,6 +155,56 @@ class ZWorkspace:
         self.sw_col = torch.empty(nnz1, **f32) if need_sw else None
         self.s_row = torch.empty(nnz1, **f32) if need_srow else None
         self.tile_flag = torch.zeros(max(ct.nrb * ct.ncb, 1), dtype=torch.int32, device=dev)
+        self.timer = None      # set to a KernelTimer to time the launches of a sweep
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are launched on (torch's
+    current stream, which is the stream handed to the C ABI)."""
+
+    def __init__(self):
+        self.records = []
+
+    def span(self, name):
+        return _Span(self, name)
+
+    def summary(self):
+        """{name: (count, mean_ms)} -- call after torch.cuda.synchronize()."""
+        acc = {}
+        for name, a, b in self.records:
+            c, t = acc.get(name, (0, 0.0))
+            acc[name] = (c + 1, t + a.elapsed_time(b))
+        return {k: (c, t / c) for k, (c, t) in acc.items()}
+
+    def reset(self):
+        self.records = []
+
+
+class _Span:
+    def __init__(self, timer, name):
+        self.timer, self.name = timer, name
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.timer.records.append((self.name, self.a, self.b))
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _span(ws, name):
+    t = getattr(ws, 'timer', None)
+    return t.span(name) if t is not None else _NoSpan()
 
 
 def factor_prep(F, logF, mask=None, mu=None):
@@ -174,13 +224,33 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat):
     factor_prep(ws.FU, log_U_hat)
     factor_prep(ws.FV, log_V_hat)
     Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
-    call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, None, ptr(ws.R), ptr(ws.s_col), None, None,
-         ptr(ws.tile_flag), K, st)
-    call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_col), None, None, ptr(log_U_hat), ptr(log_V_hat),
-         None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
-    call('oriana_col_pass', ct.c_struct, ptr(ws.s_col), ptr(ws.FU), ptr(ws.C), K, st)
+    with _span(ws, 'row_pass'):
+        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, None, ptr(ws.R), ptr(ws.s_col), None, None,
+             ptr(ws.tile_flag), K, st)
+    with _span(ws, 'fixup'):
+        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_col), None, None, ptr(log_U_hat), ptr(log_V_hat),
+             None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
+    with _span(ws, 'col_pass'):
+        call('oriana_col_pass', ct.c_struct, ptr(ws.s_col), ptr(ws.FU), ptr(ws.C), K, st)
     call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ct.n, K, 1, st)
     call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ct.m, K, 1, st)
+
+
+def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
+    """oriana_zq_gap_f32: the reference signature on dense device tensors (packs X per call)."""
+    for t in (Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
+            raise TypeError('expected 2-D C-contiguous float32 device tensors')
+    n, K = log_U_hat.shape
+    m = log_V_hat.shape[0]
+    _check_f32(Z_hat_i, (n, K)); _check_f32(Z_hat_j, (m, K)); _check_f32(log_V_hat, (m, K)); _check_f32(X, (n, m))
+    kpad(K)
+    nnz = int(torch.count_nonzero(X).item()) if X.numel() else 0
+    nbytes = int(_lib.load().oriana_zq_workspace_bytes(n, m, K, nnz + 64))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=X.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    call('oriana_zq_gap_f32', ptr(Z_hat_i), ptr(Z_hat_j), ptr(log_U_hat), ptr(log_V_hat), ptr(X), n, m, K,
+         base, nbytes, stream_ptr())
 
 
 def _check_f32(t, shape):

@@ -124,7 +124,11 @@ class FactorModel:
         NMF) so that ``np.random.seed(s)`` before the constructor gives the reference's start."""
         if init is not None:
             a1, b1 = init
-            return torch.as_tensor(np.asarray(a1, dtype=np.float64)), torch.as_tensor(np.asarray(b1, dtype=np.float64)), None
+            a1 = a1 if isinstance(a1, torch.Tensor) else torch.as_tensor(np.asarray(a1, dtype=np.float64))
+            b1 = b1 if isinstance(b1, torch.Tensor) else torch.as_tensor(np.asarray(b1, dtype=np.float64))
+            if tuple(a1.shape) != (self.n, self.k) or tuple(b1.shape) != (self.m, self.k):
+                raise ValueError('init shapes must be (n, k) and (m, k)')
+            return a1, b1, None
         if X_host is None:
             raise ValueError('init=(a1, b1) is required when the count matrix is already on the device')
         if self.world > 1:

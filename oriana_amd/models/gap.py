@@ -10,14 +10,13 @@ __all__ = ['GaP']
 class GaP(FactorModel):
 
     @staticmethod
-    def compute_Z_q_expectations(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X, workspace=None):
+    def compute_Z_q_expectations(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
         """Drop-in for the reference's loop nest (gap.py:67-80): outputs first, caller allocates,
-        callee zero-fills, returns None.  All arguments are float32 device tensors; X is dense
-        (n, m) and is packed on every call (the model itself keeps X packed across sweeps)."""
-        ws = workspace
-        if ws is None:
-            ws = engine.ZWorkspace(engine.CountTiles.from_dense(X, X.device), log_U_hat.shape[1])
-        engine.zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat)
+        callee zero-fills, returns None.  All arguments are 2-D C-contiguous float32 DEVICE tensors
+        (TypeError otherwise, like numba's explicit signature); X is dense (n, m) and is repacked on
+        every call through the stateless C entry oriana_zq_gap_f32 (the model itself keeps X packed
+        across sweeps)."""
+        engine.zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X)
 
     def update_variational_parameters(self):
         """gap.py:82-115 (E-step)."""

@@ -62,16 +62,48 @@ class SyntheticCounts:
             blk[inrow] = self.alpha[grp]
         return scale
 
-    def chunk(self, r0, r1, dtype=torch.float32):
-        """Rows [r0, r1) of this shard as a dense device matrix (deterministic in (seed, rows))."""
+    CELL = 4096     # rows per RNG cell: the data are a function of (seed, global row), not of the sharding
+
+    def _cell_rng(self, cell, salt):
         g = torch.Generator(device=self.device)
-        g.manual_seed((self.seed * 1000003 + (self.row0 + r0) * 7919 + 17) % (2 ** 62))
-        U = torch.empty(r1 - r0, self.k, dtype=torch.float32, device=self.device).exponential_(1.0, generator=g)
-        U *= self._u_scale(r0, r1)
-        lam = U @ self.V.t()
-        keep = torch.rand(r1 - r0, self.m, generator=g, device=self.device) < self.pi_d
-        x = torch.floor(lam) * keep
-        return x.to(dtype)
+        g.manual_seed((self.seed * 1000003 + cell * 7919 + salt) % (2 ** 62))
+        return g
+
+    def _cells(self, r0, r1):
+        """Global RNG cells intersecting local rows [r0, r1): (cell, global row range inside it)."""
+        g0, g1 = self.row0 + r0, self.row0 + r1
+        for cell in range(g0 // self.CELL, (g1 + self.CELL - 1) // self.CELL):
+            a = max(g0, cell * self.CELL)
+            b = min(g1, (cell + 1) * self.CELL)
+            yield cell, a, b
+
+    def chunk(self, r0, r1, dtype=torch.float32):
+        """Rows [r0, r1) of this shard as a dense device matrix (deterministic in (seed, global rows))."""
+        out = torch.empty(r1 - r0, self.m, dtype=dtype, device=self.device)
+        for cell, a, b in self._cells(r0, r1):
+            g = self._cell_rng(cell, 17)
+            c0 = cell * self.CELL
+            U = torch.empty(self.CELL, self.k, dtype=torch.float32, device=self.device).exponential_(1.0, generator=g)
+            U = U[a - c0:b - c0] * self._u_scale(a - self.row0, b - self.row0)
+            lam = U @ self.V.t()
+            g2 = self._cell_rng(cell, 29)
+            keep = torch.rand(self.CELL, self.m, generator=g2, device=self.device)[a - c0:b - c0] < self.pi_d
+            out[a - self.row0 - r0:b - self.row0 - r0] = (torch.floor(lam) * keep).to(dtype)
+        return out
+
+    def initial_shapes(self):
+        """`use_factors=False` start (gap.py:52, 62): a1 ~ Gamma(1) per local cell row, b1 ~ Gamma(1)
+        per gene (replicated).  Returns float64 device tensors (n, k), (m, k)."""
+        a1 = torch.empty(self.n, self.k, dtype=torch.float64, device=self.device)
+        for cell, a, b in self._cells(0, self.n):
+            g = self._cell_rng(cell, 43)
+            c0 = cell * self.CELL
+            e = torch.empty(self.CELL, self.k, dtype=torch.float64, device=self.device).exponential_(1.0, generator=g)
+            a1[a - self.row0:b - self.row0] = e[a - c0:b - c0]
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.seed + 977)
+        b1 = torch.empty(self.m, self.k, dtype=torch.float64, device=self.device).exponential_(1.0, generator=g)
+        return a1, b1
 
     def labels(self, r0, r1):
         rows = torch.arange(self.row0 + r0, self.row0 + r1, device=self.device)

@@ -1,0 +1,87 @@
+# -*- coding: utf-8 -*-
+"""Host logic that needs no GPU: shape algebra (bit-exact), Parameter, seeded init replay,
+row sharding bookkeeping."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden_files, load_golden
+
+
+def test_dimensions_known_answers():
+    """The doctest examples of the reference (oriana/dims.py:91-101)."""
+    from oriana_amd import Dimensions
+    dims = Dimensions({'n': 10, 'm': 5, 'p': 5, 'k': 3, 'l': 4})
+    assert repr(dims('m,k ~ d,s')) == 'Dimension mapping (5, 3) <-> (3, 5, 1)'
+    assert repr(dims('n,k ~ s,d')) == 'Dimension mapping (10, 3) <-> (10, 3, 1)'
+    assert repr(dims('m,k ~ s,d')) == 'Dimension mapping (5, 3) <-> (5, 3, 1)'
+    assert repr(dims('n,m,k ~ d,d,d')) == 'Dimension mapping (10, 5, 3) <-> (1, 150, 1)'
+    assert repr(dims('n,k,l,l ~ s,d,c,c')) == 'Dimension mapping (10, 3, 4, 4) <-> (10, 3, 16)'
+
+
+def test_dimensions_reshape_roundtrip_and_transpose():
+    """'n,m,k ~ d,s,d' (reference test/test.py:60-79): tile over m, then a non-trivial permute."""
+    from oriana_amd import Dimensions, IncompatibleShapeException
+    dims = Dimensions({'n': 2, 'm': 3, 'k': 4})
+    rel = dims('n,m,k ~ d,s,d')
+    assert rel.shape == (2, 3, 4) and rel.canonical_shape == (3, 8, 1)
+    canon = np.arange(24).reshape(3, 8, 1)
+    buf = rel.reshape_func(canon)
+    assert buf.shape == (2, 3, 4)
+    # sample axis (m) is axis 0 of the canonical array
+    for j in range(3):
+        assert np.array_equal(buf[:, j, :].reshape(-1), canon[j, :, 0])
+    assert np.array_equal(rel.inv_reshape_func(buf), canon)
+    assert dims('n,k ~ d,d').is_identity() and not rel.is_identity()
+    with pytest.raises(IncompatibleShapeException):
+        dims('n,k ~ d')
+    import torch
+    tb = rel.reshape_func(torch.from_numpy(canon))
+    assert np.array_equal(tb.numpy(), buf)
+    dims['q'] = 7
+    assert dims['q'] == 7
+
+
+def test_parameter_surface():
+    """oriana/parameters.py:8-32 surface on a torch buffer (CPU tensor here)."""
+    import torch
+    from oriana_amd import Parameter
+    p = Parameter([[0.02, 0.34], [0.62, 0.79]], device='cpu')
+    assert p.shape == (2, 2) and p.asarray().dtype == np.float64
+    assert np.array_equal(p[:], np.asarray([[0.02, 0.34], [0.62, 0.79]]))
+    p[0, 1] = 5.0
+    p[1] = np.asarray([1.0, 2.0])
+    assert np.array_equal(p.asarray(), np.asarray([[0.02, 5.0], [1.0, 2.0]]))
+    assert p[0, 1] == 5.0
+    p.buffer = np.ones((3,))
+    assert p.shape == (3,) and isinstance(p.buffer, torch.Tensor) and p.buffer.dtype == torch.float64
+    mask = np.asarray([True, False, True])
+    p[mask] = 0.5
+    assert np.array_equal(p.asarray(), np.asarray([0.5, 1.0, 0.5]))
+
+
+@pytest.mark.parametrize('path', golden_files(), ids=os.path.basename)
+def test_seeded_init_replay(path):
+    """np.random.seed(s) + the replayed constructor randomness = the reference's initial a1 / b1."""
+    from oriana_amd.models.hostinit import reference_initial_shapes
+    g = load_golden(path)
+    np.random.seed(int(g['meta/seed']) + 1)
+    a1, b1, nmf = reference_initial_shapes(str(g['meta/name']), g['X'], int(g['meta/k']), bool(g['meta/use_factors']))
+    assert np.array_equal(np.maximum(1e-15, a1), g['s0/a1'])
+    assert np.array_equal(np.maximum(1e-15, b1), g['s0/b1'])
+    assert np.array_equal(nmf[0], g['nmf/U'])
+
+
+def test_shard_rows_bookkeeping():
+    """Contiguous blocks, remainder to the last rank, exact cover -- bit-exact."""
+    from oriana_amd.dist import shard_rows
+    for n, w in ((1000000, 8), (10, 3), (7, 8), (0, 2), (257, 2), (500000, 4)):
+        spans = [shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] == b[0]
+        assert all(b - a == n // w for a, b in spans[:-1])
+    assert shard_rows(1000000, 7, 8) == (875000, 1000000)
+    with pytest.raises(ValueError):
+        shard_rows(10, 3, 3)

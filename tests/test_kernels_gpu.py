@@ -147,3 +147,23 @@ def test_zq_gap_rejects_wrong_dtype(eng):
     z = torch.zeros(4, 2, device='cuda')
     with pytest.raises(TypeError):
         eng.zq_gap(ws, z, z.clone(), z.double(), z.clone())
+
+
+def test_stateless_dropin_signature(eng):
+    """GaP.compute_Z_q_expectations(Z_i, Z_j, log_U, log_V, X): the reference's own calling
+    convention (gap.py:89-94) on device tensors, through oriana_zq_gap_f32."""
+    from oriana_amd.models import GaP
+    from oracle import cavi_oracle as co
+    g = load_golden(golden_files('gap_odd_nmf.npz')[0])
+    X = torch.from_numpy(g['X'].astype(np.float32)).cuda()
+    lu = torch.from_numpy(g['s0/log_U_hat']).cuda(); lv = torch.from_numpy(g['s0/log_V_hat']).cuda()
+    Zi = torch.full(lu.shape, 7.0, device='cuda'); Zj = torch.full(lv.shape, 7.0, device='cuda')   # callee zero-fills
+    assert GaP.compute_Z_q_expectations(Zi, Zj, lu, lv, X) is None
+    assert err_colrel(Zi.cpu().numpy(), g['kernel/Zi']) < RTOL
+    assert err_colrel(Zj.cpu().numpy(), g['kernel/Zj']) < RTOL
+    with pytest.raises(TypeError):
+        GaP.compute_Z_q_expectations(Zi, Zj, lu.double(), lv, X)
+    # all-zero and empty inputs
+    Z0 = torch.zeros_like(X)
+    GaP.compute_Z_q_expectations(Zi, Zj, lu, lv, Z0)
+    assert not Zi.any() and not Zj.any()

@@ -30,25 +30,45 @@ extern "C" {
 #define ORIANA_EKRANGE  (-2)   /* K larger than the largest compiled configuration */
 #define ORIANA_EQUIRK   (-3)   /* reference_quirks needs K <= m (zigap.py:94 reads D_hat[i, k]) */
 
-/* 8-byte record of one non-zero count, row-major inside its tile. */
+/* 8-byte record of one slot of the row-side stream.  x == 0 marks a padding slot. */
 typedef struct {
-    float    x;     /* the count, as float32 (gap.py:94 casts X to float32) */
-    uint16_t cpos;  /* position of this entry in the tile's column-major order */
+    float    x;     /* the count, as float32 (gap.py:94 casts X to float32); 0 = padding */
+    uint16_t cdst;  /* slot of this entry inside the tile's column-side region */
     uint8_t  col;   /* column inside the tile */
     uint8_t  pad;
 } oriana_rowrec;
 
-/* Tiled non-zero layout of one row shard of X.  All arrays live in device memory and are owned
- * by the caller (the Python host allocates them as torch tensors). */
+/* Tiled, sliced non-zero layout of one row shard of X (built once by oriana_pack_*).
+ *
+ * X is cut into 256 x 256 tiles (row-block-major).  Inside a tile the non-zeros are stored twice:
+ *   - row side: the tile's 256 rows form 16 slices of 16 rows.  A slice is a sequence of
+ *     "iterations" of 64 slots = 16 rows x 4 consecutive records of that row (slot = iteration*64 +
+ *     row_in_slice*4 + u); a row's records are in increasing column order; rows shorter than the
+ *     longest row of the slice are padded (x = 0).  One wave-wide 512-byte load fetches an iteration.
+ *   - column side: the same with 16-column slices; slot = iteration*64 + col_in_slice*4 + u holds
+ *     the tile row index (ridx) and, in the per-sweep array `s`, the scalar s_ij of that entry;
+ *     a column's entries are in increasing row order.  The last 64 slots of a tile's column-side
+ *     region are write-only dummies (target of the padding lanes' stores).
+ * All arrays live in device memory and are owned by the caller (the Python host allocates them as
+ * torch tensors; rowrec and ridx must be zero-filled before oriana_pack_fill). */
 typedef struct {
     int64_t n, m;                 /* rows (cells) in this shard, columns (genes) */
     int64_t nrb, ncb;             /* ceil(n / 256), ceil(m / 256) */
     int64_t nnz;                  /* non-zero entries */
-    const int64_t       *tile_off;   /* [nrb*ncb + 1] first entry of tile (rb, cb), rb-major */
-    const uint32_t      *row_ptr;    /* [nrb*ncb][257] row starts inside the tile */
-    const uint32_t      *col_ptr;    /* [nrb*ncb][257] column starts inside the tile */
-    const oriana_rowrec *rowrec;     /* [nnz] row-major records */
-    const uint8_t       *ridx;       /* [nnz] row inside the tile, column-major order */
+    int64_t rslots, cslots;       /* total slots of the row-side / column-side streams */
+    const int64_t       *roff;       /* [nrb*ncb + 1] first row-side slot of tile (rb, cb), rb-major */
+    const int64_t       *coff;       /* [nrb*ncb + 1] first column-side slot of the tile */
+    const uint32_t      *rslice;     /* [nrb*ncb][17] slot offsets of the 16-row slices inside the tile */
+    const uint32_t      *cslice;     /* [nrb*ncb][17] slot offsets of the 16-column slices inside the tile */
+    const oriana_rowrec *rowrec;     /* [rslots] */
+    const uint8_t       *ridx;       /* [cslots] row inside the tile */
+    /* Optional internal orderings (NULL = identity): packed column c holds gene col_perm[c], packed
+     * row r holds cell row_perm[r].  Sorting genes (and cells) by their non-zero count puts
+     * entries of similar density in the same tile, which shortens the padding of the slices.
+     * All dense inputs / outputs of the API stay in the caller's order: the permutation is applied
+     * by oriana_factor_prep (gather), oriana_finalize (scatter) and oriana_fixup. */
+    const int32_t       *col_perm;   /* [m] */
+    const int32_t       *row_perm;   /* [n] */
 } oriana_counts;
 
 /* Kp for a given K (0 if K is out of range). */
@@ -58,23 +78,26 @@ const char *oriana_version(void);
 
 /* ---- packing the count matrix (replaces `self.X[:].astype(np.float32)`, gap.py:94) --------
  * Two passes over dense row chunks (a chunk starts at a multiple of 256 rows):
- *   1. oriana_pack_count   -> per-tile nnz + per-tile row / column counts
- *   2. (caller) exclusive scan of tile_cnt -> tile_off
- *   3. oriana_pack_fill    -> rowrec / ridx / row_ptr / col_ptr
+ *   1. oriana_pack_count   -> per-tile nnz / slot counts and the slice offsets
+ *   2. (caller) exclusive scans of tile_rslots, tile_cslots -> roff, coff; zero-filled rowrec, ridx
+ *   3. oriana_pack_fill    -> rowrec / ridx (/ side_nz)
  * X is dense (rows, m) with leading dimension ldx (elements), float32 or (xdtype = 1) int64 /
  * (xdtype = 2) int32 / (xdtype = 3) float64.  rb0 = first row block of the chunk.
  */
 int oriana_pack_count(const void *X, int xdtype, int64_t rows, int64_t m, int64_t ldx,
                       int64_t rb0, int64_t ncb,
-                      int32_t *tile_cnt,      /* [nrb*ncb] */
-                      uint32_t *row_ptr,      /* [nrb*ncb][257]: receives per-row counts */
-                      uint32_t *col_ptr,      /* [nrb*ncb][257]: receives per-column counts */
+                      int32_t *tile_nnz,      /* [nrb*ncb] */
+                      int32_t *tile_rslots,   /* [nrb*ncb] */
+                      int32_t *tile_cslots,   /* [nrb*ncb] (includes the 64 dummy slots) */
+                      uint32_t *rslice,       /* [nrb*ncb][17] */
+                      uint32_t *cslice,       /* [nrb*ncb][17] */
                       void *stream);
 int oriana_pack_fill(const void *X, int xdtype, int64_t rows, int64_t m, int64_t ldx,
-                     int64_t rb0, int64_t ncb, const int64_t *tile_off,
-                     uint32_t *row_ptr, uint32_t *col_ptr,   /* counts in, offsets out */
+                     int64_t rb0, int64_t ncb, const int64_t *roff, const int64_t *coff,
+                     const uint32_t *rslice, const uint32_t *cslice,
                      oriana_rowrec *rowrec, uint8_t *ridx,
-                     /* optional: gather a dense (rows, m) f32 side matrix (D_hat) at the non-zeros */
+                     /* optional: gather a dense (rows, m) f32 side matrix (D_hat) at the non-zeros,
+                      * row-side slot order */
                      const float *side, int64_t ldside, float *side_nz,
                      void *stream);
 
@@ -83,9 +106,11 @@ int oriana_pack_fill(const void *X, int xdtype, int64_t rows, int64_t m, int64_t
  *   F[i, k] = exp(l[i, k] - mu[i]) * (mask ? mask[i, k] : 1),   mu[i] = max_k l[i, k],
  * the shift being undone analytically (softmax is shift invariant, gap.py:74-78).  Rows whose
  * shift is too large for the shifted form to reproduce the reference's float32 behaviour are
- * filled with NaN: every entry that touches them is evaluated by the exact slow path.
+ * zero-filled: every entry that touches them fails the den test and is evaluated by the exact slow
+ * path (oriana_fixup).
  */
 int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask,
+                       const int32_t *row_index,   /* F row i is built from logF row row_index[i] (NULL: i) */
                        int64_t r, int64_t K, void *stream);
 
 /* ---- the responsibility pass ----------------------------------------------------------------
@@ -102,35 +127,41 @@ int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask
  */
 int oriana_row_pass(const oriana_counts *cm,
                     const float *FU,        /* (n, Kp) */
-                    const float *FVden,     /* (m, Kp) */
-                    const float *FVacc,     /* (m, Kp) or NULL = FVden */
-                    const float *w_nz,      /* [nnz] per-entry weight (D_hat at the non-zeros) or NULL = 1 */
+                    const float *FV,        /* (m, Kp) */
+                    const float *w_nz,      /* [rslots] per-entry weight (D_hat at the non-zeros) or NULL = 1 */
                     float *R,               /* (n, Kp) out */
-                    float *s_col,           /* [nnz] out: s_ij (unweighted), column-major tile order */
-                    float *sw_col,          /* [nnz] out: w_ij s_ij, or NULL */
-                    float *s_row,           /* [nnz] out: s_ij row-major, or NULL */
-                    int32_t *tile_flag,     /* [nrb*ncb] out: 1 if the tile holds slow-path entries */
+                    float *s_cs,            /* [cslots] out: s_ij (unweighted), column-side slots; padding slots must hold 0 */
+                    float *sw_cs,           /* [cslots] out: w_ij s_ij (required iff w_nz) */
+                    float *s_rs,            /* [rslots] out: s_ij, row-side slots, or NULL */
+                    int32_t *tile_flag,     /* [nrb*ncb] out: 1 if the tile holds slow-path entries (zero it first) */
                     int64_t K, void *stream);
 
-int oriana_row_spmm(const oriana_counts *cm, const float *s_row, const float *w_nz,
+/* R[i,:] = sum_j w_ij s_ij FV[j,:] with s given in row-side slots (sparse models: S_hat-weighted sums). */
+int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz,
                     const float *FV, float *R, int64_t K, void *stream);
 
-int oriana_col_pass(const oriana_counts *cm, const float *s_col,
+int oriana_col_pass(const oriana_counts *cm, const float *s_cs,
                     const float *G,         /* (n, Kp) */
                     float *C,               /* (m, Kp) accumulated with atomics: zero it first */
-                    int64_t K, void *stream);
+                    int64_t K,
+                    /* optional work list [nwork][3] = (column block, first row block, end row block):
+                     * one workgroup per item; items should carry similar slot counts (genes differ
+                     * widely in density).  NULL / 0: uniform row bands. */
+                    const int32_t *work, int64_t nwork,
+                    void *stream);
 
-/* Z[i,k] = (zero_first ? 0 : Z[i,k]) + F[i,k] * R[i,k] (* mul[i,k] if mul)  -- dense (r, K) out. */
-int oriana_finalize(float *Z, const float *F, const float *R, const float *mul,
+/* Z[o,k] = (accumulate ? Z[o,k] : 0) + F[i,k] * R[i,k] (* mul[o,k] if mul), o = row_index ? row_index[i] : i
+ * -- dense (r, K) out from padded (r, Kp) in. */
+int oriana_finalize(float *Z, const float *F, const float *R, const float *mul, const int32_t *row_index,
                     int64_t r, int64_t K, int accumulate, void *stream);
 
 /* Slow path (exact reference arithmetic) for the entries flagged by oriana_row_pass.
  * variant bit 0: S_tilde / S_hat present (sparse models); bit 1: D_hat weights (w_nz);
  * bit 2: reference quirk zigap.py:94 (dq = D_hat[:, :K] dense (n, K)).
  * Adds into Zi (n, K), Zj (m, K), Zlog (m, K) (any may be NULL) and rewrites the sentinels in
- * s_col / sw_col / s_row as 0. */
+ * s_cs / sw_cs / s_rs as 0. */
 int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag,
-                 float *s_col, float *sw_col, float *s_row,
+                 float *s_cs, float *sw_cs, float *s_rs,
                  const float *logU, const float *logV,
                  const float *S_tilde, const float *S_hat,
                  const float *w_nz, const float *dq,

@@ -9,7 +9,7 @@ import os
 from ctypes import c_int, c_int64, c_void_p, c_double, c_char_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'csrc', 'liboriana_hip.so')
+LIB_PATH = os.environ.get('ORIANA_HIP_LIB') or os.path.join(HERE, 'csrc', 'liboriana_hip.so')   # env: analysis builds
 
 
 class OrianaHipError(RuntimeError):
@@ -19,8 +19,9 @@ class OrianaHipError(RuntimeError):
 class OrianaCounts(ctypes.Structure):
     """struct oriana_counts (include/oriana_hip.h)."""
     _fields_ = [('n', c_int64), ('m', c_int64), ('nrb', c_int64), ('ncb', c_int64), ('nnz', c_int64),
-                ('tile_off', c_void_p), ('row_ptr', c_void_p), ('col_ptr', c_void_p),
-                ('rowrec', c_void_p), ('ridx', c_void_p)]
+                ('rslots', c_int64), ('cslots', c_int64),
+                ('roff', c_void_p), ('coff', c_void_p), ('rslice', c_void_p), ('cslice', c_void_p),
+                ('rowrec', c_void_p), ('ridx', c_void_p), ('col_perm', c_void_p), ('row_perm', c_void_p)]
 
 
 _P = c_void_p
@@ -28,13 +29,13 @@ _I = c_int64
 _SIGS = {
     'oriana_kpad': (c_int64, [_I]),
     'oriana_version': (c_char_p, []),
-    'oriana_pack_count': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    'oriana_pack_fill': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    'oriana_factor_prep': (c_int, [_P, _P, _P, _P, _I, _I, _P]),
-    'oriana_row_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_pack_count': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'oriana_pack_fill': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'oriana_factor_prep': (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_row_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
-    'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P]),
-    'oriana_finalize': (c_int, [_P, _P, _P, _P, _I, _I, c_int, _P]),
+    'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
+    'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),
     'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _I, c_int, _P]),
     'oriana_zq_workspace_bytes': (c_int64, [_I, _I, _I, _I]),

@@ -1,4 +1,5 @@
-// pack.hip -- repack the dense count matrix X into 256 x 256 tiles of non-zero records.
+// pack.hip -- repack the dense count matrix X into the tiled, sliced non-zero layout
+// (struct oriana_counts, include/oriana_hip.h).
 //
 // Replaces `self.X[:].astype(np.float32)` (oriana/models/gap.py:94), which the reference redoes on
 // every sweep: X is constant across sweeps (gap.py:29-32), so it is converted ONCE into the layout
@@ -9,30 +10,32 @@ namespace oriana {
 
 template <typename T> __device__ __forceinline__ bool is_nz(T v) { return v != (T)0; }
 
-// exclusive scan of 256 counts held one per thread; returns the exclusive prefix, total in *total
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *total, uint32_t *sh /*[4]*/) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-    #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
+// per-tile row / column counts -> slice offsets.  cnt[256] in LDS; thread sl < 16 owns a slice.
+__device__ __forceinline__ void slice_offsets(const uint32_t *cnt, uint32_t *slice /*[17] LDS*/, int tid) {
+    __shared__ uint32_t len[16];
+    if (tid < 16) {
+        uint32_t mx = 0;
+        for (int r = 0; r < 16; ++r) mx = max(mx, cnt[tid * 16 + r]);
+        len[tid] = ((mx + 3) >> 2) * 64;            // iterations of 4 records x 16 lanes-groups
     }
-    if (lane == 63) sh[w] = inc;
     __syncthreads();
-    uint32_t base = 0;
-    for (int i = 0; i < w; ++i) base += sh[i];
-    *total = sh[0] + sh[1] + sh[2] + sh[3];
+    if (tid == 0) {
+        uint32_t o = 0;
+        for (int s = 0; s < 16; ++s) { slice[s] = o; o += len[s]; }
+        slice[16] = o;
+    }
     __syncthreads();
-    return base + inc - v;
 }
 
 // grid = (ncb, row blocks in chunk); block = 256 threads (4 waves); wave w scans rows w, w+4, ...
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_count(const T *__restrict__ X, int64_t rows, int64_t m, int64_t ldx,
-                                                    int64_t rb0, int64_t ncb, int32_t *__restrict__ tile_cnt,
-                                                    uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ col_ptr) {
+                                                    int64_t rb0, int64_t ncb, int32_t *__restrict__ tile_nnz,
+                                                    int32_t *__restrict__ tile_rslots, int32_t *__restrict__ tile_cslots,
+                                                    uint32_t *__restrict__ rslice, uint32_t *__restrict__ cslice) {
+    __shared__ uint32_t rcnt[TILE];
     __shared__ uint32_t ccnt[TILE];
+    __shared__ uint32_t rs[17], cs[17];
     __shared__ uint32_t tot[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t cb = blockIdx.x, rbl = blockIdx.y;
@@ -53,51 +56,40 @@ __global__ __launch_bounds__(256) void k_pack_count(const T *__restrict__ X, int
             rc += __popcll(mask);
             mycol[u] += nz ? 1u : 0u;
         }
-        if (lane == 0) row_ptr[t * (TILE + 1) + r] = rc;
+        if (lane == 0) rcnt[r] = rc;
         wtot += rc;
     }
     #pragma unroll
     for (int u = 0; u < 4; ++u) atomicAdd(&ccnt[u * 64 + lane], mycol[u]);
     if (lane == 0) tot[w] = wtot;
     __syncthreads();
-    col_ptr[t * (TILE + 1) + tid] = ccnt[tid];
+    slice_offsets(rcnt, rs, tid);
+    slice_offsets(ccnt, cs, tid);
+    if (tid < 17) {
+        rslice[t * 17 + tid] = rs[tid];
+        cslice[t * 17 + tid] = cs[tid];
+    }
     if (tid == 0) {
-        tile_cnt[t] = (int32_t)(tot[0] + tot[1] + tot[2] + tot[3]);
-        row_ptr[t * (TILE + 1) + TILE] = 0;
-        col_ptr[t * (TILE + 1) + TILE] = 0;
+        tile_nnz[t] = (int32_t)(tot[0] + tot[1] + tot[2] + tot[3]);
+        tile_rslots[t] = (int32_t)rs[16];
+        tile_cslots[t] = (int32_t)cs[16] + 64;      // + the write-only dummy slots
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_fill(const T *__restrict__ X, int64_t rows, int64_t m, int64_t ldx,
-                                                   int64_t rb0, int64_t ncb, const int64_t *__restrict__ tile_off,
-                                                   uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ col_ptr,
-                                                   oriana_rowrec *__restrict__ rowrec, uint8_t *__restrict__ ridx,
-                                                   const float *__restrict__ side, int64_t ldside,
-                                                   float *__restrict__ side_nz) {
-    __shared__ uint32_t rowstart[TILE + 1];
-    __shared__ uint32_t colstart[TILE + 1];
+                                                   int64_t rb0, int64_t ncb, const int64_t *__restrict__ roff,
+                                                   const int64_t *__restrict__ coff, const uint32_t *__restrict__ rslice,
+                                                   const uint32_t *__restrict__ cslice, oriana_rowrec *__restrict__ rowrec,
+                                                   uint8_t *__restrict__ ridx, const float *__restrict__ side,
+                                                   int64_t ldside, float *__restrict__ side_nz) {
     __shared__ unsigned long long bits[TILE][4];
-    __shared__ uint32_t sh[4];
+    __shared__ uint32_t rs[17], cs[17];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t cb = blockIdx.x, rbl = blockIdx.y;
     const int64_t t = (rb0 + rbl) * ncb + cb;
-    const int64_t base = tile_off[t];
-    uint32_t *rp = row_ptr + t * (TILE + 1);
-    uint32_t *cp = col_ptr + t * (TILE + 1);
-
-    // counts (from k_pack_count) -> exclusive offsets
-    uint32_t total;
-    uint32_t ex = block_scan_256(rp[tid], &total, sh);
-    rowstart[tid] = ex;
-    if (tid == 0) rowstart[TILE] = total;
-    ex = block_scan_256(cp[tid], &total, sh);
-    colstart[tid] = ex;
-    if (tid == 0) colstart[TILE] = total;
-    __syncthreads();
-    rp[tid] = rowstart[tid];
-    cp[tid] = colstart[tid];
-    if (tid == 0) { rp[TILE] = rowstart[TILE]; cp[TILE] = colstart[TILE]; }
+    const int64_t rbase = roff[t], cbase = coff[t];
+    if (tid < 17) { rs[tid] = rslice[t * 17 + tid]; cs[tid] = cslice[t * 17 + tid]; }
 
     // A: non-zero bitmask of the tile
     for (int r = w; r < TILE; r += 4) {
@@ -113,44 +105,46 @@ __global__ __launch_bounds__(256) void k_pack_fill(const T *__restrict__ X, int6
     }
     __syncthreads();
 
-    // B: thread c walks down its column; records are emitted in row-major positions, the row
-    // index list in column-major positions (both orders are sorted, hence deterministic)
+    // B: thread c walks down its column: records go to the row-side slot of (row, rank in row) and
+    // the row index to the column-side slot of (column, rank in column); both ranks follow the
+    // sorted order, so the layout (and every summation order derived from it) is deterministic
     const int c = tid;
     const int cw = c >> 6, cbit = c & 63;
     const int64_t col = cb * TILE + c;
-    uint32_t cnt = 0;
-    const uint32_t cs = colstart[c];
+    const uint32_t cstart = cs[c >> 4] + (uint32_t)(c & 15) * 4u;
+    uint32_t kc = 0;
     for (int r = 0; r < TILE; ++r) {
         const unsigned long long word = bits[r][cw];
         if ((word >> cbit) & 1ull) {
             uint32_t rank = __popcll(word & ((1ull << cbit) - 1ull));
             for (int u = 0; u < cw; ++u) rank += __popcll(bits[r][u]);
             const int64_t row = rbl * TILE + r;
-            const uint32_t rpos = rowstart[r] + rank;
-            const uint32_t cpos = cs + cnt;
-            ++cnt;
+            const uint32_t rslot = rs[r >> 4] + (rank >> 2) * 64u + (uint32_t)(r & 15) * 4u + (rank & 3u);
+            const uint32_t cslot = cstart + (kc >> 2) * 64u + (kc & 3u);
+            ++kc;
             oriana_rowrec rec;
             rec.x = (float)X[row * ldx + col];
-            rec.cpos = (uint16_t)cpos;
+            rec.cdst = (uint16_t)cslot;
             rec.col = (uint8_t)c;
             rec.pad = 0;
-            rowrec[base + rpos] = rec;
-            ridx[base + cpos] = (uint8_t)r;
-            if (side_nz) side_nz[base + rpos] = side[row * ldside + col];
+            rowrec[rbase + rslot] = rec;
+            ridx[cbase + cslot] = (uint8_t)r;
+            if (side_nz) side_nz[rbase + rslot] = side[row * ldside + col];
         }
     }
 }
 
 template <typename T>
 static int launch_count(const void *X, int64_t rows, int64_t m, int64_t ldx, int64_t rb0, int64_t ncb,
-                        int32_t *tile_cnt, uint32_t *row_ptr, uint32_t *col_ptr, hipStream_t s) {
+                        int32_t *tile_nnz, int32_t *tile_rslots, int32_t *tile_cslots, uint32_t *rslice,
+                        uint32_t *cslice, hipStream_t s) {
     const int64_t nrbl = (rows + TILE - 1) / TILE;
     if (nrbl == 0 || ncb == 0) return 0;
     for (int64_t y0 = 0; y0 < nrbl; y0 += 65535) {          // gridDim.y limit
         const int64_t ny = (nrbl - y0 < 65535) ? nrbl - y0 : 65535;
         dim3 grid((unsigned)ncb, (unsigned)ny);
         hipLaunchKernelGGL(k_pack_count<T>, grid, dim3(256), 0, s, (const T *)X + y0 * TILE * ldx,
-                           rows - y0 * TILE, m, ldx, rb0 + y0, ncb, tile_cnt, row_ptr, col_ptr);
+                           rows - y0 * TILE, m, ldx, rb0 + y0, ncb, tile_nnz, tile_rslots, tile_cslots, rslice, cslice);
     }
     ORIANA_LAUNCH_CHECK();
     return 0;
@@ -158,15 +152,16 @@ static int launch_count(const void *X, int64_t rows, int64_t m, int64_t ldx, int
 
 template <typename T>
 static int launch_fill(const void *X, int64_t rows, int64_t m, int64_t ldx, int64_t rb0, int64_t ncb,
-                       const int64_t *tile_off, uint32_t *row_ptr, uint32_t *col_ptr, oriana_rowrec *rowrec,
-                       uint8_t *ridx, const float *side, int64_t ldside, float *side_nz, hipStream_t s) {
+                       const int64_t *roff, const int64_t *coff, const uint32_t *rslice, const uint32_t *cslice,
+                       oriana_rowrec *rowrec, uint8_t *ridx, const float *side, int64_t ldside, float *side_nz,
+                       hipStream_t s) {
     const int64_t nrbl = (rows + TILE - 1) / TILE;
     if (nrbl == 0 || ncb == 0) return 0;
     for (int64_t y0 = 0; y0 < nrbl; y0 += 65535) {
         const int64_t ny = (nrbl - y0 < 65535) ? nrbl - y0 : 65535;
         dim3 grid((unsigned)ncb, (unsigned)ny);
         hipLaunchKernelGGL(k_pack_fill<T>, grid, dim3(256), 0, s, (const T *)X + y0 * TILE * ldx,
-                           rows - y0 * TILE, m, ldx, rb0 + y0, ncb, tile_off, row_ptr, col_ptr, rowrec, ridx,
+                           rows - y0 * TILE, m, ldx, rb0 + y0, ncb, roff, coff, rslice, cslice, rowrec, ridx,
                            side ? side + y0 * TILE * ldside : nullptr, ldside, side_nz);
     }
     ORIANA_LAUNCH_CHECK();
@@ -178,35 +173,39 @@ static int launch_fill(const void *X, int64_t rows, int64_t m, int64_t ldx, int6
 using namespace oriana;
 
 extern "C" int oriana_pack_count(const void *X, int xdtype, int64_t rows, int64_t m, int64_t ldx, int64_t rb0,
-                                 int64_t ncb, int32_t *tile_cnt, uint32_t *row_ptr, uint32_t *col_ptr,
-                                 void *stream) {
+                                 int64_t ncb, int32_t *tile_nnz, int32_t *tile_rslots, int32_t *tile_cslots,
+                                 uint32_t *rslice, uint32_t *cslice, void *stream) {
     if (rows < 0 || m < 0 || ldx < m || rb0 < 0 || ncb != (m + TILE - 1) / TILE) return ORIANA_EINVAL;
     if (rows == 0 || m == 0) return 0;
-    if (!X || !tile_cnt || !row_ptr || !col_ptr) return ORIANA_EINVAL;
+    if (!X || !tile_nnz || !tile_rslots || !tile_cslots || !rslice || !cslice) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+#define ORIANA_PC(T) return launch_count<T>(X, rows, m, ldx, rb0, ncb, tile_nnz, tile_rslots, tile_cslots, rslice, cslice, s)
     switch (xdtype) {
-        case 0: return launch_count<float>(X, rows, m, ldx, rb0, ncb, tile_cnt, row_ptr, col_ptr, s);
-        case 1: return launch_count<int64_t>(X, rows, m, ldx, rb0, ncb, tile_cnt, row_ptr, col_ptr, s);
-        case 2: return launch_count<int32_t>(X, rows, m, ldx, rb0, ncb, tile_cnt, row_ptr, col_ptr, s);
-        case 3: return launch_count<double>(X, rows, m, ldx, rb0, ncb, tile_cnt, row_ptr, col_ptr, s);
+        case 0: ORIANA_PC(float);
+        case 1: ORIANA_PC(int64_t);
+        case 2: ORIANA_PC(int32_t);
+        case 3: ORIANA_PC(double);
         default: return ORIANA_EINVAL;
     }
+#undef ORIANA_PC
 }
 
 extern "C" int oriana_pack_fill(const void *X, int xdtype, int64_t rows, int64_t m, int64_t ldx, int64_t rb0,
-                                int64_t ncb, const int64_t *tile_off, uint32_t *row_ptr, uint32_t *col_ptr,
-                                oriana_rowrec *rowrec, uint8_t *ridx, const float *side, int64_t ldside,
-                                float *side_nz, void *stream) {
+                                int64_t ncb, const int64_t *roff, const int64_t *coff, const uint32_t *rslice,
+                                const uint32_t *cslice, oriana_rowrec *rowrec, uint8_t *ridx, const float *side,
+                                int64_t ldside, float *side_nz, void *stream) {
     if (rows < 0 || m < 0 || ldx < m || rb0 < 0 || ncb != (m + TILE - 1) / TILE) return ORIANA_EINVAL;
     if (rows == 0 || m == 0) return 0;
-    if (!X || !tile_off || !row_ptr || !col_ptr || !rowrec || !ridx) return ORIANA_EINVAL;
+    if (!X || !roff || !coff || !rslice || !cslice || !rowrec || !ridx) return ORIANA_EINVAL;
     if ((side != nullptr) != (side_nz != nullptr)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+#define ORIANA_PF(T) return launch_fill<T>(X, rows, m, ldx, rb0, ncb, roff, coff, rslice, cslice, rowrec, ridx, side, ldside, side_nz, s)
     switch (xdtype) {
-        case 0: return launch_fill<float>(X, rows, m, ldx, rb0, ncb, tile_off, row_ptr, col_ptr, rowrec, ridx, side, ldside, side_nz, s);
-        case 1: return launch_fill<int64_t>(X, rows, m, ldx, rb0, ncb, tile_off, row_ptr, col_ptr, rowrec, ridx, side, ldside, side_nz, s);
-        case 2: return launch_fill<int32_t>(X, rows, m, ldx, rb0, ncb, tile_off, row_ptr, col_ptr, rowrec, ridx, side, ldside, side_nz, s);
-        case 3: return launch_fill<double>(X, rows, m, ldx, rb0, ncb, tile_off, row_ptr, col_ptr, rowrec, ridx, side, ldside, side_nz, s);
+        case 0: ORIANA_PF(float);
+        case 1: ORIANA_PF(int64_t);
+        case 2: ORIANA_PF(int32_t);
+        case 3: ORIANA_PF(double);
         default: return ORIANA_EINVAL;
     }
+#undef ORIANA_PF
 }

@@ -8,29 +8,49 @@
 //     Z_j[j,k] = FV[j,k] * sum_i s_ij FU[i,k]    (column pass, register accumulators)
 // which is r_ijk = x_ij e_k / sum_k e_k, e_k = exp(lu_ik + lv_jk), summed over j and over i, with
 // the shifts cancelling in the ratio.  Zero counts contribute nothing (gap.py:78) and are never
-// touched: X lives in HBM as 256 x 256 tiles of non-zero records (pack.hip).
+// touched: X lives in HBM as 256 x 256 tiles of sliced non-zero records (pack.hip).
 //
 // Mapping (wave64): a group of G lanes owns one row (row pass) or one column (column pass) for
 // the whole kernel and keeps its K-vector and its accumulator in registers, 4*T4 floats per lane
-// (Kp = 4*G*T4).  The other side's K-vectors are staged through LDS, one 256-row tile at a time,
-// and read with ds_read_b128.  No MFMA: the work is a sampled dot product per non-zero plus two
-// scaled vector adds, not a dense contraction.
+// (Kp = 4*G*T4).  The other side's K-vectors are staged through LDS, 256 rows at a time, and
+// read with ds_read_b128.  A wave streams its slice of the tile 64 slots (one 512-byte load) per
+// iteration and walks the four records of each quad with DPP broadcasts; the inner loops have no
+// data-dependent branch.  No MFMA: the work is a sampled dot product per non-zero plus two scaled
+// vector adds over the sparse support of X, not a dense contraction.
 #include "common.h"
 
+// Ablation switches for kernel analysis builds (never defined in the shipped library).
+#ifdef ORIANA_ABLATE_NOBARRIER
+#define ORIANA_SYNC() do { } while (0)
+#else
+#define ORIANA_SYNC() __syncthreads()
+#endif
+#if defined(ORIANA_ABLATE_SAMEROW)
+#define ORIANA_LDS_ROW(base, off) (lds)[(off)]                 /* every group reads image row 0: no bank conflicts */
+#elif defined(ORIANA_ABLATE_HALFLDS)
+#define ORIANA_LDS_ROW(base, off) (((tt) & 1) ? f4{1.f, 1.f, 1.f, 1.f} : (base)[(off)])   /* half the LDS reads */
+#else
+#define ORIANA_LDS_ROW(base, off) (base)[(off)]
+#endif
+
 namespace oriana {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 // factor preparation
 // ------------------------------------------------------------------------------------------
-// one wave per row; K <= 64 * PER lanes-slots
+// one wave per row
 __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, float *__restrict__ mu_out,
                                                      const float *__restrict__ logF, const float *__restrict__ mask,
-                                                     int64_t r, int K, int Kp) {
+                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= r) return;
-    const float *l = logF + row * K;
-    const float *mk = mask ? mask + row * K : nullptr;
+    const int64_t src = row_index ? (int64_t)row_index[row] : row;
+    const float *l = logF + src * K;
+    const float *mk = mask ? mask + src * K : nullptr;
     float mx = -INFINITY;
     bool bad = false;
     for (int k = lane; k < K; k += 64) {
@@ -55,247 +75,279 @@ __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, floa
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS geometry shared by the three tile kernels
+// LDS geometry shared by the tile kernels
 // ------------------------------------------------------------------------------------------
 constexpr int lds_stride_floats(int KP) { return (KP + 63) / 64 * 64; }     // rows are 256-B aligned
 constexpr int LDS_BUDGET = 160 * 1024;
-// smallest power-of-two split of the 256 staged rows such that `images` LDS images fit
-constexpr int pick_nsub(int KP, int images) {
+// smallest power-of-two split of the 256 staged rows such that the LDS image fits
+constexpr int pick_nsub(int KP) {
     int nsub = 1;
-    while ((TILE / nsub) * lds_stride_floats(KP) * 4 * images > LDS_BUDGET) nsub *= 2;
+    while ((TILE / nsub) * lds_stride_floats(KP) * 4 > LDS_BUDGET) nsub *= 2;
     return nsub;
 }
 
 template <int G>
 __device__ __forceinline__ int lds_rot(int lane) {
-    // ds_read_b128 services lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32) together; groups
-    // that are serviced together start at different 64-byte quarters of the 256-byte bank row.
-    if (G == 4) return ((lane >> 2) & 7) >> 1;
+    // ds_read_b128 is serviced in fixed 16-lane sets; quads that are serviced together must start
+    // at different 64-byte quarters of the 256-byte bank row.  Measured on MI355X with
+    // scratch/ub/lds_pat.hip (random 512-byte rows, 7 chunks): no rotation 16.5, (Q&7)>>1 6.6,
+    // this one 6.1, broadcast floor 5.4 cycles per wave-instruction.
+#if defined(ORIANA_ABLATE_ROT0)
+    return 0;
+#elif defined(ORIANA_ABLATE_ROTQ)
+    return (lane >> 2) & 3;
+#elif defined(ORIANA_ABLATE_ROTQ7)
+    return (lane >> 2) % 7;
+#endif
+    if (G == 4) { const int Q = lane >> 2; return ((Q & 1) << 1) | ((Q >> 1) & 1); }
     if (G == 8) return ((lane >> 3) & 3) >> 1;
     return 0;
 }
 
-__device__ __forceinline__ int quad_count(bool v) {
-    uint32_t c = v ? 1u : 0u;
-    c += dpp_u32<0xB1>(c);
-    c += dpp_u32<0x4E>(c);
-    return (int)c;
-}
+template <int U> __device__ __forceinline__ uint32_t qb_u32(uint32_t v) { return quad_bcast_u32<U>(v); }
+template <int U> __device__ __forceinline__ float qb_f32(float v) { return quad_bcast_f32<U>(v); }
 
 // stage `rows` factor rows starting at global row j0 (bounded by jmax) into an LDS image
 template <int KP4, int STRIDE4>
-__device__ __forceinline__ void stage_rows(float4 *img, const float *__restrict__ F, int64_t j0, int64_t jmax,
+__device__ __forceinline__ void stage_rows(f4 *img, const float *__restrict__ F, int64_t j0, int64_t jmax,
                                            int rows, int tid) {
+#ifdef ORIANA_ABLATE_NOSTAGE
+    if (j0 > 0) return;
+#endif
     for (int idx = tid; idx < rows * KP4; idx += 1024) {
         const int jr = idx / KP4, c4 = idx - jr * KP4;
         const int64_t j = j0 + jr;
-        if (j < jmax) img[jr * STRIDE4 + c4] = reinterpret_cast<const float4 *>(F)[j * KP4 + c4];
+        // rows past the end are zero-filled: padding slots point at image row 0 and must read finite values
+        img[jr * STRIDE4 + c4] = (j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + c4] : f4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// row pass:  s = x / <FU_i, FVden_j>,   R_i += w s FVacc_j
-// ------------------------------------------------------------------------------------------
-template <int G, int T4, bool SEPACC, bool HASW>
-__global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float *__restrict__ FU,
-                                                   const float *__restrict__ FVden, const float *__restrict__ FVacc,
-                                                   const float *__restrict__ w_nz, float *__restrict__ R,
-                                                   float *__restrict__ s_col, float *__restrict__ sw_col,
-                                                   float *__restrict__ s_row, int32_t *__restrict__ tile_flag) {
-    constexpr int KP = 4 * G * T4;
-    constexpr int KP4 = KP / 4;                         // float4 per factor row
-    constexpr int STRIDE4 = lds_stride_floats(KP) / 4;  // LDS row stride in float4
-    constexpr int ROWS = 1024 / G;                      // rows owned by one workgroup
-    constexpr int SPLIT = TILE / ROWS;                  // workgroups per 256-row block
-    constexpr int NSUB = pick_nsub(KP, SEPACC ? 2 : 1); // column sub-tiles per tile (LDS budget)
-    constexpr int CT = TILE / NSUB;
-    extern __shared__ float4 lds[];                     // [CT][STRIDE4] (+ [CT][STRIDE4] when SEPACC)
-    float4 *ldsA = lds + (SEPACC ? CT * STRIDE4 : 0);
+// Geometry of a wave inside the 1024-thread workgroup.
+//   RW  = rows (columns) owned by one wave = 64 / G
+//   a 16-row slice is shared by WPS = 16 / RW waves; wave `w` handles sub-slice h = w % WPS
+//   the workgroup covers 16 * RW rows = SPLIT-th part of the 256-row block
+template <int G>
+struct WaveGeo {
+    static constexpr int RW = 64 / G;
+    static constexpr int WPS = 16 / RW;
+    static constexpr int OWN = 16 * RW;          // rows owned by the workgroup
+    static constexpr int SPLIT = TILE / OWN;
+};
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int q = tid & (G - 1);
-    const int grp = tid / G;
-    const int64_t rb = blockIdx.x / SPLIT;
-    const int rl = (blockIdx.x % SPLIT) * ROWS + grp;      // row inside the 256-row block
+// ------------------------------------------------------------------------------------------
+// row pass:  s = x / <FU_i, FV_j>,   R_i += w s FV_j
+//   VAR bit 0: also write s in row-side slots (s_rs);  bit 1: per-entry weights w_nz / sw_cs
+// ------------------------------------------------------------------------------------------
+template <int G, int T4, int VAR>
+__global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float *__restrict__ FU,
+                                                   const float *__restrict__ FV, const float *__restrict__ w_nz,
+                                                   float *__restrict__ R, float *__restrict__ s_cs,
+                                                   float *__restrict__ sw_cs, float *__restrict__ s_rs,
+                                                   int32_t *__restrict__ tile_flag) {
+    constexpr bool SROW = (VAR & 1) != 0, HASW = (VAR & 2) != 0;
+    constexpr int PD = HASW ? 2 : 3;            // prefetch depth (iterations), bounded by the register budget
+    constexpr int KP = 4 * G * T4;
+    constexpr int KP4 = KP / 4;
+    constexpr int STRIDE4 = lds_stride_floats(KP) / 4;
+    constexpr int NSUB = pick_nsub(KP);
+    constexpr int CT = TILE / NSUB;
+    using Geo = WaveGeo<G>;
+    extern __shared__ f4 lds[];                 // [CT][STRIDE4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = tid & (G - 1), ql = lane & 3;
+    const int64_t rb = blockIdx.x / Geo::SPLIT;
+    const int part = blockIdx.x % Geo::SPLIT;
+    const int sl = __builtin_amdgcn_readfirstlane(part * (16 / Geo::SPLIT) + wave / Geo::WPS);   // slice of the tile
+    const int h = wave % Geo::WPS;
+    const int g = lane / G;                      // row of the wave
+    const int rl = sl * 16 + h * Geo::RW + g;    // row inside the 256-row block
     const int64_t row = rb * TILE + rl;
+    const int rec_lane = (h * Geo::RW + g) * 4 + ql;   // this lane's slot inside a 64-slot iteration
     const int rot = lds_rot<G>(lane);
 
     int choff[T4];                              // float4 offset of the chunk visited at step t
     #pragma unroll
     for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
 
-    float4 fu[T4], acc[T4];
+    f4 fu[T4], acc[T4];
     #pragma unroll
-    for (int t = 0; t < T4; ++t) {
-        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        fu[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int t = 0; t < T4; ++t) { acc[t] = f4{0.f, 0.f, 0.f, 0.f}; fu[t] = f4{0.f, 0.f, 0.f, 0.f}; }
     if (row < cm.n) {
         #pragma unroll
-        for (int t = 0; t < T4; ++t) fu[t] = reinterpret_cast<const float4 *>(FU)[row * KP4 + choff[t]];
+        for (int t = 0; t < T4; ++t) fu[t] = reinterpret_cast<const f4 *>(FU)[row * KP4 + choff[t]];
     }
+
     for (int64_t cb = 0; cb < cm.ncb; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
-        const int64_t base = cm.tile_off[t];
-        uint32_t p = cm.row_ptr[t * (TILE + 1) + rl];              // cursor over this row's records
-        const uint32_t re = cm.row_ptr[t * (TILE + 1) + rl + 1];
+        const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
+        const int niter = __builtin_amdgcn_readfirstlane((int)((s1 - s0) >> 6));
+        const int64_t rbase = cm.roff[t] + s0 + rec_lane;           // this lane's slot at iteration 0
+        const unsigned long long *recp = reinterpret_cast<const unsigned long long *>(cm.rowrec) + rbase;
+        float *sdst = s_cs + cm.coff[t];
+        float *swdst = HASW ? sw_cs + cm.coff[t] : nullptr;
+        const uint32_t dummy = cm.cslice[t * 17 + 16] + lane;       // write-only slot of the tile
+        bool bad = false;
         for (int csub = 0; csub < NSUB; ++csub) {
-            __syncthreads();                    // everybody is done with the previous image
-            stage_rows<KP4, STRIDE4>(lds, FVden, cb * TILE + csub * CT, cm.m, CT, tid);
-            if (SEPACC) stage_rows<KP4, STRIDE4>(ldsA, FVacc, cb * TILE + csub * CT, cm.m, CT, tid);
-            __syncthreads();
-            const uint32_t lim = (uint32_t)(csub + 1) * CT;        // records with col < lim are stageable
-            while (p < re) {
-                // each quad fetches four consecutive records of its row (all quads of a group
-                // fetch the same four), then walks them with quad broadcasts
-                const uint32_t mine = p + (lane & 3);
-                unsigned long long raw = 0ull;
-                float wv = 1.0f;
-                if (mine < re) {
-                    raw = reinterpret_cast<const unsigned long long *>(cm.rowrec)[base + mine];
-                    if (HASW) wv = w_nz[base + mine];
-                }
-                const uint32_t rx = (uint32_t)raw, rm = (uint32_t)(raw >> 32);
-                // records are column-sorted: the ones inside this sub-tile form a prefix
-                const int cnt = quad_count(mine < re && (NSUB == 1 || ((rm >> 16) & 0xFFu) < lim));
-                float sbuf = 0.f;   // s of the record this lane fetched (for the row-major store)
+            // record prefetch ring: the next PD iterations are always in flight (global-load latency
+            // is several iterations long); the first ones are issued before the factor rows are
+            // staged, so their latency hides behind the staging
+            unsigned long long rawq[PD];
+            float wq[PD];
+            #pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int id = (d < niter) ? d : (niter > 0 ? niter - 1 : 0);
+                rawq[d] = 0ull; wq[d] = 1.0f;
+                if (niter > 0) { rawq[d] = recp[(int64_t)id * 64]; if (HASW) wq[d] = w_nz[rbase + (int64_t)id * 64]; }
+            }
+            ORIANA_SYNC();                    // everybody is done with the previous image
+            stage_rows<KP4, STRIDE4>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
+            ORIANA_SYNC();
+            for (int it = 0; it < niter; ++it) {
+                uint32_t rx = (uint32_t)rawq[0], rm = (uint32_t)(rawq[0] >> 32);
+                const float wcur = wq[0];
                 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u < cnt) {
-                        uint32_t bx = 0, bm = 0; float bw = 1.f;
-                        if (u == 0) { bx = quad_bcast_u32<0>(rx); bm = quad_bcast_u32<0>(rm); bw = quad_bcast_f32<0>(wv); }
-                        if (u == 1) { bx = quad_bcast_u32<1>(rx); bm = quad_bcast_u32<1>(rm); bw = quad_bcast_f32<1>(wv); }
-                        if (u == 2) { bx = quad_bcast_u32<2>(rx); bm = quad_bcast_u32<2>(rm); bw = quad_bcast_f32<2>(wv); }
-                        if (u == 3) { bx = quad_bcast_u32<3>(rx); bm = quad_bcast_u32<3>(rm); bw = quad_bcast_f32<3>(wv); }
-                        const float x = __uint_as_float(bx);
-                        const uint32_t cpos = bm & 0xFFFFu;
-                        const int col = (int)((bm >> 16) & 0xFFu) - csub * CT;
-                        const float4 *vrow = lds + col * STRIDE4;
-                        float4 v[T4];
-                        float den = 0.f;
-                        #pragma unroll
-                        for (int tt = 0; tt < T4; ++tt) {
-                            v[tt] = vrow[choff[tt]];
-                            den = fmaf(fu[tt].x, v[tt].x, den);
-                            den = fmaf(fu[tt].y, v[tt].y, den);
-                            den = fmaf(fu[tt].z, v[tt].z, den);
-                            den = fmaf(fu[tt].w, v[tt].w, den);
-                        }
-                        den = group_sum<G>(den);
-                        const bool ok = den >= DEN_MIN;          // false for 0, tiny and NaN
-                        float s = ok ? x * __builtin_amdgcn_rcpf(den) : 0.f;
-                        // one Newton step on the quotient: s <- s + (x - s*den) / den  (keeps s within 1 ulp)
-                        if (ok) s = fmaf(fmaf(-s, den, x), __builtin_amdgcn_rcpf(den), s);
-                        const float sw = HASW ? s * bw : s;
-                        if (SEPACC) {
-                            const float4 *arow = ldsA + col * STRIDE4;
-                            #pragma unroll
-                            for (int tt = 0; tt < T4; ++tt) v[tt] = arow[choff[tt]];
-                        }
-                        #pragma unroll
-                        for (int tt = 0; tt < T4; ++tt) {
-                            acc[tt].x = fmaf(sw, v[tt].x, acc[tt].x);
-                            acc[tt].y = fmaf(sw, v[tt].y, acc[tt].y);
-                            acc[tt].z = fmaf(sw, v[tt].z, acc[tt].z);
-                            acc[tt].w = fmaf(sw, v[tt].w, acc[tt].w);
-                        }
-                        const float sout = ok ? s : NAN;          // NaN = "evaluate me exactly" sentinel
-                        if (q == 0) {
-                            s_col[base + cpos] = sout;
-                            if (sw_col) sw_col[base + cpos] = ok ? sw : NAN;
-                        }
-                        if ((lane & 3) == u) sbuf = sout;
-                        if (!ok && q == 0) tile_flag[t] = 1;
+                for (int d = 0; d + 1 < PD; ++d) { rawq[d] = rawq[d + 1]; wq[d] = wq[d + 1]; }
+                // refill the ring (clamped: past the end it re-reads the last iteration)
+                const int nx = (it + PD < niter) ? it + PD : niter - 1;
+                rawq[PD - 1] = recp[(int64_t)nx * 64];
+                if (HASW) wq[PD - 1] = w_nz[rbase + (int64_t)nx * 64];
+                float sbuf = 0.f;
+#define ORIANA_ROW_STEP(U)                                                                            \
+                {                                                                                     \
+                    const uint32_t bm = qb_u32<U>(rm);                                                \
+                    const float x = __uint_as_float(qb_u32<U>(rx));                                   \
+                    int col = (int)((bm >> 16) & 0xFFu);                                              \
+                    bool valid = (x != 0.f);                                                          \
+                    if (NSUB > 1) { valid = valid && (col / CT == csub); col &= (CT - 1); }           \
+                    const f4 *vrow = lds + col * STRIDE4;                                             \
+                    f4 v[T4];                                                                         \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) v[tt] = ORIANA_LDS_ROW(vrow, choff[tt]);        \
+                    f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};                                            \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        d01 = __builtin_elementwise_fma(fu[tt].xy, v[tt].xy, d01);                    \
+                        d23 = __builtin_elementwise_fma(fu[tt].zw, v[tt].zw, d23);                    \
+                    }                                                                                 \
+                    const f2 dd = d01 + d23;                                                          \
+                    const float den = group_sum<G>(dd.x + dd.y);                                      \
+                    const bool ok = den >= DEN_MIN;          /* false for 0, tiny and NaN */          \
+                    const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;             \
+                    const float sw = HASW ? s * qb_f32<U>(wcur) : s;                                  \
+                    const f2 ss = {sw, sw};                                                           \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);             \
+                        acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);             \
+                    }                                                                                 \
+                    const bool slow = valid && !ok;          /* NaN = "evaluate me exactly" */       \
+                    bad = bad || slow;                                                                \
+                    const float sout = slow ? NAN : s;                                                \
+                    const uint32_t off = valid ? (bm & 0xFFFFu) : dummy;                              \
+                    sdst[off] = sout;                                                                 \
+                    if (HASW) swdst[off] = slow ? NAN : sw;                                           \
+                    if (SROW) sbuf = (ql == U) ? sout : sbuf;                                         \
+                    /* step fence: one step's K-vector live at a time (keeps the kernel spill-free) */ \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(acc[tt]));  \
+                    asm volatile("" : "+v"(rm), "+v"(rx));                                            \
+                }
+                ORIANA_ROW_STEP(0)
+                ORIANA_ROW_STEP(1)
+                ORIANA_ROW_STEP(2)
+                ORIANA_ROW_STEP(3)
+#undef ORIANA_ROW_STEP
+                if (SROW) {
+                    // row-side copy of s (one coalesced store per iteration).  With column sub-tiles
+                    // an entry is valid in exactly one of them: later sub-tiles only add their own.
+                    if (q < 4) {
+                        float *dst = s_rs + rbase + (int64_t)it * 64;
+                        if (NSUB == 1 || csub == 0) *dst = sbuf;
+                        else if (sbuf != 0.f) *dst = sbuf;
                     }
                 }
-                if (s_row && q < 4 && (lane & 3) < cnt) s_row[base + mine] = sbuf;
-                p += cnt;
-                if (cnt < 4) break;             // end of the row or of the sub-tile
             }
         }
+        if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n) {
         #pragma unroll
-        for (int t = 0; t < T4; ++t) reinterpret_cast<float4 *>(R)[row * KP4 + choff[t]] = acc[t];
+        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + choff[t]] = acc[t];
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// row SpMM with given s (row-major):  R_i = sum_j w s FV_j      (sparse models: S_hat-weighted sums)
+// row SpMM with given s (row-side slots):  R_i = sum_j w s FV_j
 // ------------------------------------------------------------------------------------------
 template <int G, int T4, bool HASW>
-__global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float *__restrict__ s_row,
+__global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float *__restrict__ s_rs,
                                                    const float *__restrict__ w_nz, const float *__restrict__ FV,
                                                    float *__restrict__ R) {
     constexpr int KP = 4 * G * T4;
     constexpr int KP4 = KP / 4;
     constexpr int STRIDE4 = lds_stride_floats(KP) / 4;
-    constexpr int ROWS = 1024 / G;
-    constexpr int SPLIT = TILE / ROWS;
-    constexpr int NSUB = pick_nsub(KP, 1);
+    constexpr int NSUB = pick_nsub(KP);
     constexpr int CT = TILE / NSUB;
-    extern __shared__ float4 lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int q = tid & (G - 1);
-    const int grp = tid / G;
-    const int64_t rb = blockIdx.x / SPLIT;
-    const int rl = (blockIdx.x % SPLIT) * ROWS + grp;
+    using Geo = WaveGeo<G>;
+    extern __shared__ f4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = tid & (G - 1), ql = lane & 3;
+    const int64_t rb = blockIdx.x / Geo::SPLIT;
+    const int part = blockIdx.x % Geo::SPLIT;
+    const int sl = __builtin_amdgcn_readfirstlane(part * (16 / Geo::SPLIT) + wave / Geo::WPS);
+    const int h = wave % Geo::WPS;
+    const int g = lane / G;
+    const int rl = sl * 16 + h * Geo::RW + g;
     const int64_t row = rb * TILE + rl;
+    const int rec_lane = (h * Geo::RW + g) * 4 + ql;
     const int rot = lds_rot<G>(lane);
     int choff[T4];
     #pragma unroll
     for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
-    float4 acc[T4];
+    f4 acc[T4];
     #pragma unroll
-    for (int t = 0; t < T4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
     for (int64_t cb = 0; cb < cm.ncb; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
-        const int64_t base = cm.tile_off[t];
-        uint32_t p = cm.row_ptr[t * (TILE + 1) + rl];
-        const uint32_t re = cm.row_ptr[t * (TILE + 1) + rl + 1];
+        const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
+        const int niter = __builtin_amdgcn_readfirstlane((int)((s1 - s0) >> 6));
+        const int64_t rbase = cm.roff[t] + s0 + rec_lane;
+        const unsigned long long *recp = reinterpret_cast<const unsigned long long *>(cm.rowrec) + rbase;
         for (int csub = 0; csub < NSUB; ++csub) {
-            __syncthreads();
+            uint32_t rm = 0; float sv = 0.f;
+            if (niter > 0) { rm = (uint32_t)(recp[0] >> 32); sv = s_rs[rbase]; if (HASW) sv *= w_nz[rbase]; }
+            ORIANA_SYNC();
             stage_rows<KP4, STRIDE4>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
-            __syncthreads();
-            const uint32_t lim = (uint32_t)(csub + 1) * CT;
-            while (p < re) {
-                const uint32_t mine = p + (lane & 3);
-                uint32_t rm = 0; float sv = 0.f;
-                if (mine < re) {
-                    rm = (uint32_t)(reinterpret_cast<const unsigned long long *>(cm.rowrec)[base + mine] >> 32);
-                    sv = s_row[base + mine];
-                    if (HASW) sv *= w_nz[base + mine];
+            ORIANA_SYNC();
+            for (int it = 0; it < niter; ++it) {
+                const uint32_t rmc = rm; const float svc = sv;
+                const int nx = (it + 1 < niter) ? it + 1 : it;
+                rm = (uint32_t)(recp[(int64_t)nx * 64] >> 32);
+                sv = s_rs[rbase + (int64_t)nx * 64];
+                if (HASW) sv *= w_nz[rbase + (int64_t)nx * 64];
+#define ORIANA_SPMM_STEP(U)                                                                           \
+                {                                                                                     \
+                    const uint32_t bm = qb_u32<U>(rmc);                                               \
+                    float s = qb_f32<U>(svc);                                                         \
+                    int col = (int)((bm >> 16) & 0xFFu);                                              \
+                    if (NSUB > 1) { if (col / CT != csub) s = 0.f; col &= (CT - 1); }                  \
+                    const f4 *vrow = lds + col * STRIDE4;                                             \
+                    const f2 ss = {s, s};                                                             \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        const f4 v = ORIANA_LDS_ROW(vrow, choff[tt]);                                                 \
+                        acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                 \
+                        acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                 \
+                    }                                                                                 \
                 }
-                const int cnt = quad_count(mine < re && (NSUB == 1 || ((rm >> 16) & 0xFFu) < lim));
-                #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u < cnt) {
-                        uint32_t bm = 0; float s = 0.f;
-                        if (u == 0) { bm = quad_bcast_u32<0>(rm); s = quad_bcast_f32<0>(sv); }
-                        if (u == 1) { bm = quad_bcast_u32<1>(rm); s = quad_bcast_f32<1>(sv); }
-                        if (u == 2) { bm = quad_bcast_u32<2>(rm); s = quad_bcast_f32<2>(sv); }
-                        if (u == 3) { bm = quad_bcast_u32<3>(rm); s = quad_bcast_f32<3>(sv); }
-                        const int col = (int)((bm >> 16) & 0xFFu) - csub * CT;
-                        const float4 *vrow = lds + col * STRIDE4;
-                        #pragma unroll
-                        for (int tt = 0; tt < T4; ++tt) {
-                            const float4 v = vrow[choff[tt]];
-                            acc[tt].x = fmaf(s, v.x, acc[tt].x);
-                            acc[tt].y = fmaf(s, v.y, acc[tt].y);
-                            acc[tt].z = fmaf(s, v.z, acc[tt].z);
-                            acc[tt].w = fmaf(s, v.w, acc[tt].w);
-                        }
-                    }
-                }
-                p += cnt;
-                if (cnt < 4) break;
+                ORIANA_SPMM_STEP(0)
+                ORIANA_SPMM_STEP(1)
+                ORIANA_SPMM_STEP(2)
+                ORIANA_SPMM_STEP(3)
+#undef ORIANA_SPMM_STEP
             }
         }
     }
     if (row < cm.n) {
         #pragma unroll
-        for (int t = 0; t < T4; ++t) reinterpret_cast<float4 *>(R)[row * KP4 + choff[t]] = acc[t];
+        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + choff[t]] = acc[t];
     }
 }
 
@@ -303,70 +355,103 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
 // column pass:  C_j += sum_i s_ij G_i      (grid.y = row bands, combined with float atomics)
 // ------------------------------------------------------------------------------------------
 template <int G, int T4>
-__global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float *__restrict__ s_col,
+__global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float *__restrict__ s_cs,
                                                    const float *__restrict__ Gm, float *__restrict__ C,
-                                                   int64_t rb_per_band) {
+                                                   const int32_t *__restrict__ work, int64_t rb_per_band) {
     constexpr int KP = 4 * G * T4;
     constexpr int KP4 = KP / 4;
     constexpr int STRIDE4 = lds_stride_floats(KP) / 4;
-    constexpr int COLS = 1024 / G;
-    constexpr int SPLIT = TILE / COLS;
-    constexpr int NSUB = pick_nsub(KP, 1);
+    constexpr int NSUB = pick_nsub(KP);
     constexpr int RT = TILE / NSUB;
-    extern __shared__ float4 lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int q = tid & (G - 1);
-    const int grp = tid / G;
-    const int64_t cb = blockIdx.x / SPLIT;
-    const int cl = (blockIdx.x % SPLIT) * COLS + grp;
+    constexpr int CPD = 4;                      // prefetch depth (iterations)
+    using Geo = WaveGeo<G>;
+    extern __shared__ f4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = tid & (G - 1), ql = lane & 3;
+    // work item: a column block and a band of row blocks.  With a work list (built at pack time
+    // from the tile sizes) every item carries about the same number of slots; without one,
+    // grid.y enumerates uniform bands.
+    const int64_t item = blockIdx.x / Geo::SPLIT;
+    const int part = blockIdx.x % Geo::SPLIT;
+    int64_t cb, rb0, rb1;
+    if (work) {
+        cb = work[item * 3 + 0]; rb0 = work[item * 3 + 1]; rb1 = work[item * 3 + 2];
+    } else {
+        cb = item;
+        rb0 = (int64_t)blockIdx.y * rb_per_band;
+        rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
+    }
+    const int sl = __builtin_amdgcn_readfirstlane(part * (16 / Geo::SPLIT) + wave / Geo::WPS);
+    const int h = wave % Geo::WPS;
+    const int g = lane / G;
+    const int cl = sl * 16 + h * Geo::RW + g;    // column inside the 256-column block
     const int64_t col = cb * TILE + cl;
+    const int ent_lane = (h * Geo::RW + g) * 4 + ql;
     const int rot = lds_rot<G>(lane);
     int choff[T4];
     #pragma unroll
     for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
-    float4 acc[T4];
+    f4 acc[T4];
     #pragma unroll
-    for (int t = 0; t < T4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int64_t rb0 = (int64_t)blockIdx.y * rb_per_band;
-    const int64_t rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
     for (int64_t rb = rb0; rb < rb1; ++rb) {
         const int64_t t = rb * cm.ncb + cb;
-        const int64_t base = cm.tile_off[t];
-        uint32_t p = cm.col_ptr[t * (TILE + 1) + cl];
-        const uint32_t ce = cm.col_ptr[t * (TILE + 1) + cl + 1];
+        const uint32_t s0 = cm.cslice[t * 17 + sl], s1 = cm.cslice[t * 17 + sl + 1];
+        const int niter = __builtin_amdgcn_readfirstlane((int)((s1 - s0) >> 6));
+        const int64_t cbase = cm.coff[t] + s0 + ent_lane;
         for (int rsub = 0; rsub < NSUB; ++rsub) {
-            __syncthreads();
-            stage_rows<KP4, STRIDE4>(lds, Gm, rb * TILE + rsub * RT, cm.n, RT, tid);
-            __syncthreads();
-            const uint32_t lim = (uint32_t)(rsub + 1) * RT;
-            while (p < ce) {
-                const uint32_t mine = p + (lane & 3);
-                float sv = 0.f; uint32_t rv = 0;
-                if (mine < ce) { sv = s_col[base + mine]; rv = cm.ridx[base + mine]; }
-                const int cnt = quad_count(mine < ce && (NSUB == 1 || rv < lim));   // rows are sorted
-                #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (u < cnt) {
-                        float s = 0.f; uint32_t r = 0;
-                        if (u == 0) { s = quad_bcast_f32<0>(sv); r = quad_bcast_u32<0>(rv); }
-                        if (u == 1) { s = quad_bcast_f32<1>(sv); r = quad_bcast_u32<1>(rv); }
-                        if (u == 2) { s = quad_bcast_f32<2>(sv); r = quad_bcast_u32<2>(rv); }
-                        if (u == 3) { s = quad_bcast_f32<3>(sv); r = quad_bcast_u32<3>(rv); }
-                        const float4 *vrow = lds + ((int)r - rsub * RT) * STRIDE4;
-                        #pragma unroll
-                        for (int tt = 0; tt < T4; ++tt) {
-                            const float4 v = vrow[choff[tt]];
-                            acc[tt].x = fmaf(s, v.x, acc[tt].x);
-                            acc[tt].y = fmaf(s, v.y, acc[tt].y);
-                            acc[tt].z = fmaf(s, v.z, acc[tt].z);
-                            acc[tt].w = fmaf(s, v.w, acc[tt].w);
-                        }
-                    }
-                }
-                p += cnt;
-                if (cnt < 4) break;
+            // prefetch ring over the next CPD iterations (s and the row index of each slot)
+            float svq[CPD]; uint32_t rvq[CPD];
+            #pragma unroll
+            for (int d = 0; d < CPD; ++d) {
+                const int id = (d < niter) ? d : (niter > 0 ? niter - 1 : 0);
+                svq[d] = 0.f; rvq[d] = 0;
+                if (niter > 0) { svq[d] = s_cs[cbase + (int64_t)id * 64]; rvq[d] = cm.ridx[cbase + (int64_t)id * 64]; }
             }
+            ORIANA_SYNC();
+            stage_rows<KP4, STRIDE4>(lds, Gm, rb * TILE + rsub * RT, cm.n, RT, tid);
+            ORIANA_SYNC();
+            // Software pipeline over the steps: the K-vector of step k+1 is read from LDS while the
+            // FMAs of step k run (two register images vA / vB), so each wave always has LDS reads in
+            // flight.  The first image of an iteration is loaded during the previous one.
+            f4 vA[T4], vB[T4];
+#define ORIANA_COL_LOAD(V, U, SRC_R)                                                                  \
+            {                                                                                         \
+                int r = (int)qb_u32<U>(SRC_R);                                                        \
+                if (NSUB > 1) r &= (RT - 1);                                                          \
+                const f4 *vrow = lds + r * STRIDE4;                                                   \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) V[tt] = ORIANA_LDS_ROW(vrow, choff[tt]); \
+            }
+#define ORIANA_COL_FMA(V, U, SRC_S, SRC_R)                                                            \
+            {                                                                                         \
+                float s = qb_f32<U>(SRC_S);                                                           \
+                if (NSUB > 1) { if ((int)qb_u32<U>(SRC_R) / RT != rsub) s = 0.f; }                     \
+                const f2 ss = {s, s};                                                                 \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
+                    acc[tt].xy = __builtin_elementwise_fma(ss, V[tt].xy, acc[tt].xy);                 \
+                    acc[tt].zw = __builtin_elementwise_fma(ss, V[tt].zw, acc[tt].zw);                 \
+                }                                                                                     \
+            }
+            if (niter > 0) ORIANA_COL_LOAD(vA, 0, rvq[0])
+            for (int it = 0; it < niter; ++it) {
+                const float svc = svq[0]; const uint32_t rvc = rvq[0];
+                #pragma unroll
+                for (int d = 0; d + 1 < CPD; ++d) { svq[d] = svq[d + 1]; rvq[d] = rvq[d + 1]; }
+                const int nx = (it + CPD < niter) ? it + CPD : niter - 1;
+                svq[CPD - 1] = s_cs[cbase + (int64_t)nx * 64];
+                rvq[CPD - 1] = cm.ridx[cbase + (int64_t)nx * 64];
+                ORIANA_COL_LOAD(vB, 1, rvc)
+                ORIANA_COL_FMA(vA, 0, svc, rvc)
+                ORIANA_COL_LOAD(vA, 2, rvc)
+                ORIANA_COL_FMA(vB, 1, svc, rvc)
+                ORIANA_COL_LOAD(vB, 3, rvc)
+                ORIANA_COL_FMA(vA, 2, svc, rvc)
+                ORIANA_COL_LOAD(vA, 0, rvq[0])          // first step of the next iteration (padding-safe: row 0)
+                ORIANA_COL_FMA(vB, 3, svc, rvc)
+            }
+#undef ORIANA_COL_LOAD
+#undef ORIANA_COL_FMA
         }
     }
     if (col < cm.m) {
@@ -387,23 +472,25 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const float *__restrict__ F,
                                                   const float *__restrict__ R, const float *__restrict__ mul,
-                                                  int64_t r, int K, int Kp, int accumulate) {
+                                                  const int32_t *__restrict__ row_index, int64_t r, int K, int Kp,
+                                                  int accumulate) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= r * K) return;
     const int64_t row = idx / K;
     const int k = (int)(idx - row * K);
+    const int64_t o = (row_index ? (int64_t)row_index[row] : row) * K + k;
     float v = F[row * Kp + k] * R[row * Kp + k];
-    if (mul) v *= mul[idx];
-    Z[idx] = accumulate ? Z[idx] + v : v;
+    if (mul) v *= mul[o];
+    Z[o] = accumulate ? Z[o] + v : v;
 }
 
 // ------------------------------------------------------------------------------------------
 // fix-up: exact reference arithmetic for the entries flagged with the NaN sentinel
 // ------------------------------------------------------------------------------------------
-// grid = tiles; block = 256 threads, thread r walks row r of the tile.
+// grid = tiles; block = 256 threads striding over the row-side slots of a flagged tile.
 __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *__restrict__ tile_flag,
-                                               float *__restrict__ s_col, float *__restrict__ sw_col,
-                                               float *__restrict__ s_row, const float *__restrict__ logU,
+                                               float *__restrict__ s_cs, float *__restrict__ sw_cs,
+                                               float *__restrict__ s_rs, const float *__restrict__ logU,
                                                const float *__restrict__ logV, const float *__restrict__ S_tilde,
                                                const float *__restrict__ S_hat, const float *__restrict__ w_nz,
                                                const float *__restrict__ dq, float *__restrict__ Zi,
@@ -411,55 +498,59 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
     const int64_t t = blockIdx.x;
     if (tile_flag[t] == 0) return;
     const int64_t rb = t / cm.ncb, cb = t - rb * cm.ncb;
-    const int rl = threadIdx.x;
-    const int64_t i = rb * TILE + rl;
-    if (i >= cm.n) return;
-    const int64_t base = cm.tile_off[t];
-    const uint32_t rs = cm.row_ptr[t * (TILE + 1) + rl], re = cm.row_ptr[t * (TILE + 1) + rl + 1];
-    const float *lu = logU + i * K;
-    for (uint32_t p = rs; p < re; ++p) {
-        const oriana_rowrec rec = cm.rowrec[base + p];
-        const float s = s_col[base + rec.cpos];
-        if (s == s) continue;                                   // not a sentinel
-        const int64_t j = cb * TILE + rec.col;
-        const float *lv = logV + j * K;
-        const float *st = S_tilde ? S_tilde + j * K : nullptr;
-        const float *sh = S_hat ? S_hat + j * K : nullptr;
-        const float x = rec.x;
-        const float w = w_nz ? w_nz[base + p] : 1.0f;
-        // den = sum_k exp(lu + lv) [* S_tilde], float32, left to right (gap.py:74-76)
-        float den = 0.f;
-        for (int k = 0; k < K; ++k) {
-            float e = expf(lu[k] + lv[k]);
-            if (st) e *= st[k];
-            den += e;
+    const int64_t rbase = cm.roff[t], cbase = cm.coff[t];
+    for (int sl = 0; sl < 16; ++sl) {
+        const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
+        for (uint32_t slot = s0 + threadIdx.x; slot < s1; slot += 256) {
+            const oriana_rowrec rec = cm.rowrec[rbase + slot];
+            if (rec.x == 0.f) continue;                              // padding
+            const float s = s_cs[cbase + rec.cdst];
+            if (s == s) continue;                                    // not a sentinel
+            const int rl = sl * 16 + (int)(((slot - s0) & 63u) >> 2);
+            const int64_t ip = rb * TILE + rl;                       // packed row / column
+            const int64_t jp = cb * TILE + rec.col;
+            const int64_t i = cm.row_perm ? (int64_t)cm.row_perm[ip] : ip;   // caller's row / gene
+            const int64_t j = cm.col_perm ? (int64_t)cm.col_perm[jp] : jp;
+            const float *lu = logU + i * K;
+            const float *lv = logV + j * K;
+            const float *st = S_tilde ? S_tilde + j * K : nullptr;
+            const float *sh = S_hat ? S_hat + j * K : nullptr;
+            const float x = rec.x;
+            const float w = w_nz ? w_nz[rbase + slot] : 1.0f;
+            // den = sum_k exp(lu + lv) [* S_tilde], float32, left to right (gap.py:74-76)
+            float den = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float e = expf(lu[k] + lv[k]);
+                if (st) e *= st[k];
+                den += e;
+            }
+            den = (den > 0.f) ? den : 1.0f;
+            for (int k = 0; k < K; ++k) {
+                const float ls = lu[k] + lv[k];
+                float e = expf(ls);
+                if (st) e *= st[k];
+                const float expectation = (x * e) / den;            // gap.py:78
+                if (Zi) {
+                    float wi = w;
+                    if (sh) wi = w_nz ? w * sh[k] : sh[k];          // sparse_zigap.py:114 / sparse_gap.py:95
+                    const float v = (w_nz || sh) ? wi * expectation : expectation;
+                    if (v != 0.f) atomicAdd(&Zi[i * K + k], v);
+                }
+                if (Zj) {
+                    float v = expectation;
+                    if (quirk && dq) v = dq[i * K + k] * expectation;   // zigap.py:94 (D_hat[i, k])
+                    else if (w_nz) v = w * expectation;                 // sparse_zigap.py:115
+                    if (v != 0.f) atomicAdd(&Zj[j * K + k], v);
+                }
+                if (Zlog) {
+                    const float v = (w_nz ? w * expectation : expectation) * ls;   // zigap.py:95
+                    if (v != 0.f) atomicAdd(&Zlog[j * K + k], v);
+                }
+            }
+            s_cs[cbase + rec.cdst] = 0.f;
+            if (sw_cs) sw_cs[cbase + rec.cdst] = 0.f;
+            if (s_rs) s_rs[rbase + slot] = 0.f;
         }
-        den = (den > 0.f) ? den : 1.0f;
-        for (int k = 0; k < K; ++k) {
-            const float ls = lu[k] + lv[k];
-            float e = expf(ls);
-            if (st) e *= st[k];
-            const float expectation = (x * e) / den;            // gap.py:78
-            if (Zi) {
-                float wi = w;
-                if (sh) wi = w_nz ? w * sh[k] : sh[k];          // sparse_zigap.py:114 / sparse_gap.py:95
-                const float v = (w_nz || sh) ? wi * expectation : expectation;
-                if (v != 0.f) atomicAdd(&Zi[i * K + k], v);
-            }
-            if (Zj) {
-                float v = expectation;
-                if (quirk && dq) v = dq[i * K + k] * expectation;   // zigap.py:94 (D_hat[i, k])
-                else if (w_nz) v = w * expectation;                 // sparse_zigap.py:115
-                if (v != 0.f) atomicAdd(&Zj[j * K + k], v);
-            }
-            if (Zlog) {
-                const float v = (w_nz ? w * expectation : expectation) * ls;   // zigap.py:95
-                if (v != 0.f) atomicAdd(&Zlog[j * K + k], v);
-            }
-        }
-        s_col[base + rec.cpos] = 0.f;
-        if (sw_col) sw_col[base + rec.cpos] = 0.f;
-        if (s_row) s_row[base + p] = 0.f;
     }
 }
 
@@ -511,56 +602,62 @@ static int set_lds(KernelT kern, size_t bytes) {
     return 0;
 }
 
-static inline size_t lds_bytes(int G, int T4, int images) {
+static inline size_t lds_bytes(int G, int T4) {
     const int KP = 4 * G * T4;
-    return (size_t)(TILE / pick_nsub(KP, images)) * lds_stride_floats(KP) * sizeof(float) * images;
+    return (size_t)(TILE / pick_nsub(KP)) * lds_stride_floats(KP) * sizeof(float);
 }
 
 template <int G, int T4>
-static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FVden, const float *FVacc,
-                           const float *w_nz, float *R, float *s_col, float *sw_col, float *s_row,
-                           int32_t *tile_flag, hipStream_t s) {
-    constexpr int SPLIT = TILE / (1024 / G);
-    const dim3 grid((unsigned)(cm->nrb * SPLIT)), block(1024);
-    const bool sep = FVacc != nullptr && FVacc != FVden;
-    const bool hw = w_nz != nullptr;
-    const size_t lb = lds_bytes(G, T4, sep ? 2 : 1);
+static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
+                           float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s) {
+    const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
+    const size_t lb = lds_bytes(G, T4);
+    const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
-#define ORIANA_RP(SEP, HW)                                                                            \
-    rc = set_lds(k_row_pass<G, T4, SEP, HW>, lb);                                                     \
+#define ORIANA_RP(V)                                                                                  \
+    rc = set_lds(k_row_pass<G, T4, V>, lb);                                                           \
     if (rc) return rc;                                                                                \
-    hipLaunchKernelGGL((k_row_pass<G, T4, SEP, HW>), grid, block, lb, s, *cm, FU, FVden, FVacc, w_nz, \
-                       R, s_col, sw_col, s_row, tile_flag)
-    if (sep && hw) { ORIANA_RP(true, true); }
-    else if (sep) { ORIANA_RP(true, false); }
-    else if (hw) { ORIANA_RP(false, true); }
-    else { ORIANA_RP(false, false); }
+    hipLaunchKernelGGL((k_row_pass<G, T4, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
+    if (var == 0) { ORIANA_RP(0); }
+    else if (var == 1) { ORIANA_RP(1); }
+    else if (var == 2) { ORIANA_RP(2); }
+    else { ORIANA_RP(3); }
 #undef ORIANA_RP
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
 template <int G, int T4>
-static int launch_row_spmm(const oriana_counts *cm, const float *s_row, const float *w_nz, const float *FV,
+static int launch_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz, const float *FV,
                            float *R, hipStream_t s) {
-    constexpr int SPLIT = TILE / (1024 / G);
-    const dim3 grid((unsigned)(cm->nrb * SPLIT)), block(1024);
-    const size_t lb = lds_bytes(G, T4, 1);
+    const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
+    const size_t lb = lds_bytes(G, T4);
     int rc;
     if (w_nz) {
         rc = set_lds(k_row_spmm<G, T4, true>, lb); if (rc) return rc;
-        hipLaunchKernelGGL((k_row_spmm<G, T4, true>), grid, block, lb, s, *cm, s_row, w_nz, FV, R);
+        hipLaunchKernelGGL((k_row_spmm<G, T4, true>), grid, block, lb, s, *cm, s_rs, w_nz, FV, R);
     } else {
         rc = set_lds(k_row_spmm<G, T4, false>, lb); if (rc) return rc;
-        hipLaunchKernelGGL((k_row_spmm<G, T4, false>), grid, block, lb, s, *cm, s_row, w_nz, FV, R);
+        hipLaunchKernelGGL((k_row_spmm<G, T4, false>), grid, block, lb, s, *cm, s_rs, w_nz, FV, R);
     }
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
 template <int G, int T4>
-static int launch_col_pass(const oriana_counts *cm, const float *s_col, const float *Gm, float *C, hipStream_t s) {
-    constexpr int SPLIT = TILE / (1024 / G);
+static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C,
+                           const int32_t *work, int64_t nwork, hipStream_t s) {
+    constexpr int SPLIT = WaveGeo<G>::SPLIT;
+    const size_t lbw = lds_bytes(G, T4);
+    if (work) {
+        if (nwork <= 0) return 0;
+        int rcw = set_lds(k_col_pass<G, T4>, lbw);
+        if (rcw) return rcw;
+        hipLaunchKernelGGL((k_col_pass<G, T4>), dim3((unsigned)(nwork * SPLIT)), dim3(1024), lbw, s, *cm, s_cs, Gm, C,
+                           work, (int64_t)0);
+        ORIANA_LAUNCH_CHECK();
+        return 0;
+    }
     // enough row bands to fill the chip (>= ~1024 workgroups) without shrinking a band below 8 tiles
     int64_t nb = (1024 + cm->ncb * SPLIT - 1) / (cm->ncb * SPLIT);
     int64_t maxb = (cm->nrb + 7) / 8;
@@ -570,10 +667,10 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_col, const fl
     const int64_t per = (cm->nrb + nb - 1) / nb;
     nb = (cm->nrb + per - 1) / per;
     const dim3 grid((unsigned)(cm->ncb * SPLIT), (unsigned)nb), block(1024);
-    const size_t lb = lds_bytes(G, T4, 1);
+    const size_t lb = lds_bytes(G, T4);
     int rc = set_lds(k_col_pass<G, T4>, lb);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_col_pass<G, T4>), grid, block, lb, s, *cm, s_col, Gm, C, per);
+    hipLaunchKernelGGL((k_col_pass<G, T4>), grid, block, lb, s, *cm, s_cs, Gm, C, (const int32_t *)nullptr, per);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
@@ -588,74 +685,77 @@ extern "C" int64_t oriana_kpad(int64_t K) {
     return 4 * c.G * c.T4;
 }
 
-extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.1"; }
+extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.2"; }
 
 static bool counts_ok(const oriana_counts *cm) {
     if (!cm || cm->n < 0 || cm->m < 0) return false;
     if (cm->nrb != (cm->n + TILE - 1) / TILE || cm->ncb != (cm->m + TILE - 1) / TILE) return false;
-    if (cm->nrb * cm->ncb > 0 && (!cm->tile_off || !cm->row_ptr || !cm->col_ptr)) return false;
-    if (cm->nnz > 0 && (!cm->rowrec || !cm->ridx)) return false;
+    if (cm->nrb * cm->ncb > 0 && (!cm->roff || !cm->coff || !cm->rslice || !cm->cslice)) return false;
+    if (cm->rslots > 0 && !cm->rowrec) return false;
+    if (cm->cslots > 0 && !cm->ridx) return false;
     return true;
 }
 
-extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask, int64_t r,
-                                  int64_t K, void *stream) {
+extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask,
+                                  const int32_t *row_index, int64_t r, int64_t K, void *stream) {
     const int64_t Kp = oriana_kpad(K);
     if (r < 0 || K <= 0) return ORIANA_EINVAL;
     if (Kp == 0) return ORIANA_EKRANGE;
     if (r == 0) return 0;
     if (!F || !logF) return ORIANA_EINVAL;
     hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((r + 3) / 4)), dim3(256), 0, (hipStream_t)stream, F, mu,
-                       logF, mask, r, (int)K, (int)Kp);
+                       logF, mask, row_index, r, (int)K, (int)Kp);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const float *FVden, const float *FVacc,
-                               const float *w_nz, float *R, float *s_col, float *sw_col, float *s_row,
-                               int32_t *tile_flag, int64_t K, void *stream) {
+extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz,
+                               float *R, float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, int64_t K,
+                               void *stream) {
     if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
     KCfg cfg;
     if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
     if (cm->n == 0) return 0;
-    if (!FU || !R || (cm->m > 0 && !FVden) || (cm->nnz > 0 && (!s_col || !tile_flag))) return ORIANA_EINVAL;
+    if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
+    if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T) return launch_row_pass<G, T>(cm, FU, FVden, FVacc, w_nz, R, s_col, sw_col, s_row, tile_flag, s)
+#define CALL(G, T) return launch_row_pass<G, T>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
 }
 
-extern "C" int oriana_row_spmm(const oriana_counts *cm, const float *s_row, const float *w_nz, const float *FV,
+extern "C" int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz, const float *FV,
                                float *R, int64_t K, void *stream) {
     if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
     KCfg cfg;
     if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
     if (cm->n == 0) return 0;
-    if (!R || (cm->m > 0 && !FV) || (cm->nnz > 0 && !s_row)) return ORIANA_EINVAL;
+    if (!R || (cm->m > 0 && !FV) || (cm->rslots > 0 && !s_rs)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T) return launch_row_spmm<G, T>(cm, s_row, w_nz, FV, R, s)
+#define CALL(G, T) return launch_row_spmm<G, T>(cm, s_rs, w_nz, FV, R, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
 }
 
-extern "C" int oriana_col_pass(const oriana_counts *cm, const float *s_col, const float *Gm, float *C, int64_t K,
-                               void *stream) {
+extern "C" int oriana_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C, int64_t K,
+                               const int32_t *work, int64_t nwork, void *stream) {
     if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
     KCfg cfg;
     if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
     if (cm->n == 0 || cm->m == 0) return 0;
-    if (!Gm || !C || (cm->nnz > 0 && !s_col)) return ORIANA_EINVAL;
+    if (!Gm || !C || !s_cs) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T) return launch_col_pass<G, T>(cm, s_col, Gm, C, s)
+    if (nwork < 0 || (work == nullptr && nwork != 0)) return ORIANA_EINVAL;
+#define CALL(G, T) return launch_col_pass<G, T>(cm, s_cs, Gm, C, work, nwork, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
 }
 
-extern "C" int oriana_finalize(float *Z, const float *F, const float *R, const float *mul, int64_t r, int64_t K,
-                               int accumulate, void *stream) {
+extern "C" int oriana_finalize(float *Z, const float *F, const float *R, const float *mul,
+                               const int32_t *row_index, int64_t r, int64_t K, int accumulate, void *stream) {
     const int64_t Kp = oriana_kpad(K);
     if (r < 0 || K <= 0) return ORIANA_EINVAL;
     if (Kp == 0) return ORIANA_EKRANGE;
@@ -663,23 +763,23 @@ extern "C" int oriana_finalize(float *Z, const float *F, const float *R, const f
     if (!Z || !F || !R) return ORIANA_EINVAL;
     const int64_t tot = r * K;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, F, R,
-                       mul, r, (int)K, (int)Kp, accumulate);
+                       mul, row_index, r, (int)K, (int)Kp, accumulate);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag, float *s_col, float *sw_col,
-                            float *s_row, const float *logU, const float *logV, const float *S_tilde,
+extern "C" int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag, float *s_cs, float *sw_cs,
+                            float *s_rs, const float *logU, const float *logV, const float *S_tilde,
                             const float *S_hat, const float *w_nz, const float *dq, float *Zi, float *Zj,
                             float *Zlog, int64_t K, int variant, void *stream) {
     if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
     const int64_t nt = cm->nrb * cm->ncb;
     if (nt == 0 || cm->nnz == 0) return 0;
-    if (!tile_flag || !s_col || !logU || !logV) return ORIANA_EINVAL;
+    if (!tile_flag || !s_cs || !logU || !logV) return ORIANA_EINVAL;
     const int quirk = (variant & 4) ? 1 : 0;
     if (quirk && (!dq || K > cm->m)) return ORIANA_EQUIRK;
-    hipLaunchKernelGGL(k_fixup, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, tile_flag, s_col,
-                       sw_col, s_row, logU, logV, S_tilde, S_hat, w_nz, dq, Zi, Zj, Zlog, (int)K, quirk);
+    hipLaunchKernelGGL(k_fixup, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, tile_flag, s_cs,
+                       sw_cs, s_rs, logU, logV, S_tilde, S_hat, w_nz, dq, Zi, Zj, Zlog, (int)K, quirk);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

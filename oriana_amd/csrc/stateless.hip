@@ -36,34 +36,45 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t *__restrict__ off, 
 
 struct WsLayout {
     int64_t nt, Kp;
-    size_t tile_cnt, tile_off, row_ptr, col_ptr, tile_flag, rowrec, ridx, s_col, FU, FV, R, C, total;
+    size_t tile_nnz, tile_rslots, tile_cslots, roff, coff, rslice, cslice, tile_flag, totals, rowrec, ridx, s_cs,
+        FU, FV, R, C, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static WsLayout ws_layout(int64_t n, int64_t m, int64_t K, int64_t nnz_bound) {
+// rslot_cap / cslot_cap: capacities of the row-side / column-side slot arrays
+static WsLayout ws_layout(int64_t n, int64_t m, int64_t K, int64_t rslot_cap, int64_t cslot_cap) {
     WsLayout L;
     const int64_t nrb = (n + TILE - 1) / TILE, ncb = (m + TILE - 1) / TILE;
     L.nt = nrb * ncb;
     L.Kp = oriana_kpad(K);
     size_t o = 0;
-    const int64_t nt1 = L.nt > 0 ? L.nt : 1, nz1 = nnz_bound > 0 ? nnz_bound : 1;
+    const int64_t nt1 = L.nt > 0 ? L.nt : 1;
+    const int64_t rs1 = rslot_cap > 0 ? rslot_cap : 1, cs1 = cslot_cap > 0 ? cslot_cap : 1;
     const int64_t n1 = n > 0 ? n : 1, m1 = m > 0 ? m : 1;
-    L.tile_cnt = o;  o = align256(o + sizeof(int32_t) * nt1);
-    L.tile_off = o;  o = align256(o + sizeof(int64_t) * (nt1 + 1));
-    L.row_ptr = o;   o = align256(o + sizeof(uint32_t) * nt1 * (TILE + 1));
-    L.col_ptr = o;   o = align256(o + sizeof(uint32_t) * nt1 * (TILE + 1));
-    L.tile_flag = o; o = align256(o + sizeof(int32_t) * nt1);
-    L.rowrec = o;    o = align256(o + sizeof(oriana_rowrec) * nz1);
-    L.ridx = o;      o = align256(o + nz1);
-    L.s_col = o;     o = align256(o + sizeof(float) * nz1);
-    L.FU = o;        o = align256(o + sizeof(float) * n1 * L.Kp);
-    L.FV = o;        o = align256(o + sizeof(float) * m1 * L.Kp);
-    L.R = o;         o = align256(o + sizeof(float) * n1 * L.Kp);
-    L.C = o;         o = align256(o + sizeof(float) * m1 * L.Kp);
+    L.tile_nnz = o;    o = align256(o + sizeof(int32_t) * nt1);
+    L.tile_rslots = o; o = align256(o + sizeof(int32_t) * nt1);
+    L.tile_cslots = o; o = align256(o + sizeof(int32_t) * nt1);
+    L.roff = o;        o = align256(o + sizeof(int64_t) * (nt1 + 1));
+    L.coff = o;        o = align256(o + sizeof(int64_t) * (nt1 + 1));
+    L.rslice = o;      o = align256(o + sizeof(uint32_t) * nt1 * 17);
+    L.cslice = o;      o = align256(o + sizeof(uint32_t) * nt1 * 17);
+    L.tile_flag = o;   o = align256(o + sizeof(int32_t) * nt1);
+    L.totals = o;      o = align256(o + sizeof(int64_t) * 4);
+    L.rowrec = o;      o = align256(o + sizeof(oriana_rowrec) * rs1);
+    L.ridx = o;        o = align256(o + cs1);
+    L.s_cs = o;        o = align256(o + sizeof(float) * cs1);
+    L.FU = o;          o = align256(o + sizeof(float) * n1 * L.Kp);
+    L.FV = o;          o = align256(o + sizeof(float) * m1 * L.Kp);
+    L.R = o;           o = align256(o + sizeof(float) * n1 * L.Kp);
+    L.C = o;           o = align256(o + sizeof(float) * m1 * L.Kp);
     L.total = o;
     return L;
 }
+
+// Slot capacities that are always sufficient for `nnz_bound` non-zeros: a slice iteration holds 64
+// slots and is opened by at least one record, and each tile carries 64 dummy slots.
+static inline int64_t slot_bound(int64_t nnz_bound) { return 64 * nnz_bound; }
 
 }  // namespace oriana
 
@@ -71,7 +82,12 @@ using namespace oriana;
 
 extern "C" int64_t oriana_zq_workspace_bytes(int64_t n, int64_t m, int64_t K, int64_t nnz_bound) {
     if (n < 0 || m < 0 || nnz_bound < 0 || oriana_kpad(K) == 0) return 0;
-    return (int64_t)ws_layout(n, m, K, nnz_bound).total;
+    const int64_t nt = ((n + TILE - 1) / TILE) * ((m + TILE - 1) / TILE);
+    // worst case: every record alone in its slice iteration; capped by the dense tile capacity
+    int64_t cap = slot_bound(nnz_bound);
+    const int64_t dense = nt * 65536;
+    if (cap > dense) cap = dense;
+    return (int64_t)ws_layout(n, m, K, cap, cap + 64 * nt).total;
 }
 
 extern "C" int oriana_zq_gap_f32(float *Z_hat_i, float *Z_hat_j, const float *log_U_hat, const float *log_V_hat,
@@ -87,49 +103,53 @@ extern "C" int oriana_zq_gap_f32(float *Z_hat_i, float *Z_hat_j, const float *lo
     if (m > 0) ORIANA_HIP_CHECK(hipMemsetAsync(Z_hat_j, 0, sizeof(float) * m * K, s));
     if (n == 0 || m == 0) return 0;
     if (!X || !ws || ((uintptr_t)ws & 255)) return ORIANA_EINVAL;
-    // the workspace must at least hold the layout with zero records; its record capacity follows
-    const WsLayout L0 = ws_layout(n, m, K, 0);
+    const int64_t nrb = (n + TILE - 1) / TILE, ncb = (m + TILE - 1) / TILE, nt = nrb * ncb;
+    // fixed-size part first: counts, offsets, slice tables
+    const WsLayout L0 = ws_layout(n, m, K, 0, 0);
     if ((size_t)ws_bytes < L0.total) return ORIANA_EINVAL;
-    // largest nnz_bound whose layout fits in ws_bytes: 8 + 1 + 4 bytes per record plus alignment
-    int64_t cap = ((int64_t)ws_bytes - (int64_t)L0.total) / 13;
-    while (cap > 0 && ws_layout(n, m, K, cap).total > (size_t)ws_bytes) cap -= 64;
-    if (cap < 0) cap = 0;
-    const WsLayout L = ws_layout(n, m, K, cap);
     char *b = (char *)ws;
-    int32_t *tile_cnt = (int32_t *)(b + L.tile_cnt);
-    int64_t *tile_off = (int64_t *)(b + L.tile_off);
-    uint32_t *row_ptr = (uint32_t *)(b + L.row_ptr), *col_ptr = (uint32_t *)(b + L.col_ptr);
-    int32_t *tile_flag = (int32_t *)(b + L.tile_flag);
+    int32_t *tile_nnz = (int32_t *)(b + L0.tile_nnz), *tile_rslots = (int32_t *)(b + L0.tile_rslots);
+    int32_t *tile_cslots = (int32_t *)(b + L0.tile_cslots), *tile_flag = (int32_t *)(b + L0.tile_flag);
+    int64_t *roff = (int64_t *)(b + L0.roff), *coff = (int64_t *)(b + L0.coff);
+    uint32_t *rslice = (uint32_t *)(b + L0.rslice), *cslice = (uint32_t *)(b + L0.cslice);
+
+    int rc = oriana_pack_count(X, 0, n, m, m, 0, ncb, tile_nnz, tile_rslots, tile_cslots, rslice, cslice, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, roff, tile_rslots, nt);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, coff, tile_cslots, nt);
+    ORIANA_LAUNCH_CHECK();
+    // the one host synchronisation of this entry point: the slot totals size the record arrays
+    int64_t tot[2] = {0, 0};
+    ORIANA_HIP_CHECK(hipMemcpyAsync(&tot[0], roff + nt, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    ORIANA_HIP_CHECK(hipMemcpyAsync(&tot[1], coff + nt, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    ORIANA_HIP_CHECK(hipStreamSynchronize(s));
+    const WsLayout L = ws_layout(n, m, K, tot[0], tot[1]);
+    if (L.total > (size_t)ws_bytes) return ORIANA_EINVAL;
     oriana_rowrec *rowrec = (oriana_rowrec *)(b + L.rowrec);
     uint8_t *ridx = (uint8_t *)(b + L.ridx);
-    float *s_col = (float *)(b + L.s_col), *FU = (float *)(b + L.FU), *FV = (float *)(b + L.FV);
+    float *s_cs = (float *)(b + L.s_cs), *FU = (float *)(b + L.FU), *FV = (float *)(b + L.FV);
     float *R = (float *)(b + L.R), *C = (float *)(b + L.C);
-    const int64_t nrb = (n + TILE - 1) / TILE, ncb = (m + TILE - 1) / TILE;
-
-    int rc = oriana_pack_count(X, 0, n, m, m, 0, ncb, tile_cnt, row_ptr, col_ptr, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_off, tile_cnt, L.nt);
-    ORIANA_LAUNCH_CHECK();
-    // the one host synchronisation of this entry point: nnz decides whether the workspace is large enough
-    int64_t nnz = 0;
-    ORIANA_HIP_CHECK(hipMemcpyAsync(&nnz, tile_off + L.nt, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    ORIANA_HIP_CHECK(hipStreamSynchronize(s));
-    if (nnz > cap) return ORIANA_EINVAL;
-    rc = oriana_pack_fill(X, 0, n, m, m, 0, ncb, tile_off, row_ptr, col_ptr, rowrec, ridx, nullptr, 0, nullptr, stream);
+    // padding slots: x == 0 records, row index 0, s == 0
+    ORIANA_HIP_CHECK(hipMemsetAsync(rowrec, 0, sizeof(oriana_rowrec) * (tot[0] > 0 ? tot[0] : 1), s));
+    ORIANA_HIP_CHECK(hipMemsetAsync(ridx, 0, tot[1] > 0 ? tot[1] : 1, s));
+    ORIANA_HIP_CHECK(hipMemsetAsync(s_cs, 0, sizeof(float) * (tot[1] > 0 ? tot[1] : 1), s));
+    rc = oriana_pack_fill(X, 0, n, m, m, 0, ncb, roff, coff, rslice, cslice, rowrec, ridx, nullptr, 0, nullptr, stream);
     if (rc) return rc;
     oriana_counts cm;
-    cm.n = n; cm.m = m; cm.nrb = nrb; cm.ncb = ncb; cm.nnz = nnz;
-    cm.tile_off = tile_off; cm.row_ptr = row_ptr; cm.col_ptr = col_ptr; cm.rowrec = rowrec; cm.ridx = ridx;
+    cm.n = n; cm.m = m; cm.nrb = nrb; cm.ncb = ncb; cm.nnz = 1;   /* >0: lets oriana_fixup look at the flags */
+    cm.rslots = tot[0]; cm.cslots = tot[1];
+    cm.roff = roff; cm.coff = coff; cm.rslice = rslice; cm.cslice = cslice; cm.rowrec = rowrec; cm.ridx = ridx;
+    cm.col_perm = nullptr; cm.row_perm = nullptr;
 
-    if ((rc = oriana_factor_prep(FU, nullptr, log_U_hat, nullptr, n, K, stream))) return rc;
-    if ((rc = oriana_factor_prep(FV, nullptr, log_V_hat, nullptr, m, K, stream))) return rc;
+    if ((rc = oriana_factor_prep(FU, nullptr, log_U_hat, nullptr, nullptr, n, K, stream))) return rc;
+    if ((rc = oriana_factor_prep(FV, nullptr, log_V_hat, nullptr, nullptr, m, K, stream))) return rc;
     ORIANA_HIP_CHECK(hipMemsetAsync(C, 0, sizeof(float) * m * L.Kp, s));
-    ORIANA_HIP_CHECK(hipMemsetAsync(tile_flag, 0, sizeof(int32_t) * L.nt, s));
-    if ((rc = oriana_row_pass(&cm, FU, FV, nullptr, nullptr, R, s_col, nullptr, nullptr, tile_flag, K, stream))) return rc;
-    if ((rc = oriana_fixup(&cm, tile_flag, s_col, nullptr, nullptr, log_U_hat, log_V_hat, nullptr, nullptr, nullptr,
+    ORIANA_HIP_CHECK(hipMemsetAsync(tile_flag, 0, sizeof(int32_t) * nt, s));
+    if ((rc = oriana_row_pass(&cm, FU, FV, nullptr, R, s_cs, nullptr, nullptr, tile_flag, K, stream))) return rc;
+    if ((rc = oriana_fixup(&cm, tile_flag, s_cs, nullptr, nullptr, log_U_hat, log_V_hat, nullptr, nullptr, nullptr,
                            nullptr, Z_hat_i, Z_hat_j, nullptr, K, 0, stream))) return rc;
-    if ((rc = oriana_col_pass(&cm, s_col, FU, C, K, stream))) return rc;
-    if ((rc = oriana_finalize(Z_hat_i, FU, R, nullptr, n, K, 1, stream))) return rc;
-    if ((rc = oriana_finalize(Z_hat_j, FV, C, nullptr, m, K, 1, stream))) return rc;
+    if ((rc = oriana_col_pass(&cm, s_cs, FU, C, K, nullptr, 0, stream))) return rc;
+    if ((rc = oriana_finalize(Z_hat_i, FU, R, nullptr, nullptr, n, K, 1, stream))) return rc;
+    if ((rc = oriana_finalize(Z_hat_j, FV, C, nullptr, nullptr, m, K, 1, stream))) return rc;
     return 0;
 }

@@ -32,7 +32,7 @@ def _as_device_chunk(X, r0, r1, device):
 
 
 class CountTiles:
-    """The count matrix X of one row shard, resident in HBM as 256 x 256 tiles of non-zero records
+    """The count matrix X of one row shard, resident in HBM in the tiled, sliced non-zero layout
     (struct oriana_counts).  Built once: X is constant across sweeps (reference gap.py:29-32)."""
 
     def __init__(self, n, m, device):
@@ -40,60 +40,120 @@ class CountTiles:
         self.device = torch.device(device)
         self.nrb = (self.n + TILE - 1) // TILE
         self.ncb = (self.m + TILE - 1) // TILE
-        nt = self.nrb * self.ncb
-        self.tile_cnt = torch.zeros(max(nt, 1), dtype=torch.int32, device=self.device)
-        self.row_ptr = torch.zeros(max(nt, 1) * (TILE + 1), dtype=torch.int32, device=self.device)
-        self.col_ptr = torch.zeros(max(nt, 1) * (TILE + 1), dtype=torch.int32, device=self.device)
-        self.tile_off = None
-        self.rowrec = None
-        self.ridx = None
-        self.nnz = 0
+        nt = max(self.nrb * self.ncb, 1)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.tile_nnz = torch.zeros(nt, **i32)
+        self.tile_rslots = torch.zeros(nt, **i32)
+        self.tile_cslots = torch.zeros(nt, **i32)
+        self.rslice = torch.zeros(nt * 17, **i32)
+        self.cslice = torch.zeros(nt * 17, **i32)
+        self.roff = self.coff = None
+        self.rowrec = self.ridx = None
+        self.nnz = self.rslots = self.cslots = 0
+        self.col_perm = None      # int32 [m]: packed column c holds gene col_perm[c] (None = identity)
+        self.row_perm = None
+        self.side_nz = None
+        self.col_work = None
         self._struct = None
 
     # ---- building -------------------------------------------------------------------------
+    def set_col_order(self, col_nnz):
+        """Pack genes in decreasing order of their non-zero count (`col_nnz`: int64 [m], already
+        summed over all row shards): tiles then hold columns of similar density, which shortens
+        the padding of the slices.  Internal only -- every dense input / output of the API stays
+        in the caller's gene order."""
+        order = torch.argsort(col_nnz.to(self.device), descending=True, stable=True)
+        self.col_perm = order.to(torch.int32).contiguous()
+
+    def _permute(self, chunk):
+        if self.col_perm is None:
+            return chunk
+        return chunk.index_select(1, self.col_perm.to(torch.int64)).contiguous()
+
     def count_chunk(self, chunk, r0):
+        chunk = self._permute(chunk)
         assert r0 % TILE == 0 and chunk.is_contiguous() and chunk.shape[1] == self.m
         call('oriana_pack_count', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.m, chunk.stride(0),
-             r0 // TILE, self.ncb, ptr(self.tile_cnt), ptr(self.row_ptr), ptr(self.col_ptr), stream_ptr())
+             r0 // TILE, self.ncb, ptr(self.tile_nnz), ptr(self.tile_rslots), ptr(self.tile_cslots),
+             ptr(self.rslice), ptr(self.cslice), stream_ptr())
 
     def finish_count(self):
         nt = self.nrb * self.ncb
-        off = torch.zeros(nt + 1, dtype=torch.int64, device=self.device)
+        i64 = dict(dtype=torch.int64, device=self.device)
+        self.roff = torch.zeros(nt + 1, **i64)
+        self.coff = torch.zeros(nt + 1, **i64)
         if nt:
-            off[1:] = torch.cumsum(self.tile_cnt[:nt].to(torch.int64), dim=0)
-        self.tile_off = off
-        self.nnz = int(off[-1].item())
-        self.rowrec = torch.empty(max(self.nnz, 1), dtype=torch.int64, device=self.device)   # 8-byte records
-        self.ridx = torch.empty(max(self.nnz, 1), dtype=torch.uint8, device=self.device)
+            self.roff[1:] = torch.cumsum(self.tile_rslots[:nt].to(torch.int64), dim=0)
+            self.coff[1:] = torch.cumsum(self.tile_cslots[:nt].to(torch.int64), dim=0)
+        tot = torch.stack([self.roff[-1], self.coff[-1], self.tile_nnz[:max(nt, 1)].to(torch.int64).sum()]).tolist()
+        self.rslots, self.cslots, self.nnz = int(tot[0]), int(tot[1]), int(tot[2]) if nt else 0
+        # padding slots are recognised by x == 0 / read row index 0: zero-fill before the fill pass
+        self.rowrec = torch.zeros(max(self.rslots, 1), **i64)                                   # 8-byte records
+        self.ridx = torch.zeros(max(self.cslots, 1), dtype=torch.uint8, device=self.device)
 
     def fill_chunk(self, chunk, r0, side=None, side_nz=None):
+        chunk = self._permute(chunk)
+        if side is not None:
+            side = self._permute(side)
         assert r0 % TILE == 0 and chunk.is_contiguous()
         call('oriana_pack_fill', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.m, chunk.stride(0),
-             r0 // TILE, self.ncb, ptr(self.tile_off), ptr(self.row_ptr), ptr(self.col_ptr), ptr(self.rowrec),
-             ptr(self.ridx), ptr(side), side.stride(0) if side is not None else 0, ptr(side_nz), stream_ptr())
+             r0 // TILE, self.ncb, ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
+             ptr(self.rowrec), ptr(self.ridx), ptr(side), side.stride(0) if side is not None else 0, ptr(side_nz),
+             stream_ptr())
+
+    def _build_col_work(self, target_items=2048):
+        """Work list of the column pass: (column block, row-block range) items of about equal slot
+        count, longest first.  Genes differ widely in density, so uniform bands would leave the
+        chip waiting for the densest column block."""
+        nt = self.nrb * self.ncb
+        if nt == 0 or self.cslots == 0:
+            self.col_work = None
+            return
+        per_cb = self.tile_cslots[:nt].view(self.nrb, self.ncb).to(torch.int64).sum(0).cpu().numpy()
+        target = max(1.0, float(per_cb.sum()) / target_items)
+        items = []
+        for cb in range(self.ncb):
+            nb = int(min(self.nrb, max(1, round(per_cb[cb] / target))))
+            edges = np.linspace(0, self.nrb, nb + 1).round().astype(np.int64)
+            for a, b in zip(edges[:-1], edges[1:]):
+                if b > a:
+                    items.append((per_cb[cb] * (b - a) / self.nrb, cb, int(a), int(b)))
+        items.sort(key=lambda x: -x[0])
+        arr = np.asarray([[c, a, b] for _, c, a, b in items], dtype=np.int32)
+        self.col_work = torch.from_numpy(arr).to(self.device).contiguous()
 
     def finish(self):
-        self._struct = OrianaCounts(self.n, self.m, self.nrb, self.ncb, self.nnz, ptr(self.tile_off),
-                                    ptr(self.row_ptr), ptr(self.col_ptr), ptr(self.rowrec), ptr(self.ridx))
+        self._build_col_work()
+        self.tile_rslots = self.tile_cslots = None
+        self._struct = OrianaCounts(self.n, self.m, self.nrb, self.ncb, self.nnz, self.rslots, self.cslots,
+                                    ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
+                                    ptr(self.rowrec), ptr(self.ridx), ptr(self.col_perm), ptr(self.row_perm))
         return self
 
     @classmethod
-    def from_dense(cls, X, device='cuda', chunk_bytes=1 << 30, side=None):
+    def from_dense(cls, X, device='cuda', chunk_bytes=1 << 30, side=None, sort_cols=True, reduce_fn=None):
         """Pack a dense (n, m) matrix (NumPy or torch, host or device).  `side`: optional dense
-        (n, m) float32 DEVICE matrix gathered at the non-zeros (returned as .side_nz)."""
+        (n, m) float32 DEVICE matrix gathered at the non-zeros (returned as .side_nz, row-side
+        slots).  `reduce_fn`: sums the per-gene counts over row shards (all-reduce) so that every
+        rank packs the genes in the same order."""
         n, m = X.shape
         self = cls(n, m, device)
         if n == 0 or m == 0:
             self.finish_count()
-            self.side_nz = None
             return self.finish()
         rows = max(TILE, (chunk_bytes // max(1, m * 8)) // TILE * TILE)
+        if sort_cols:
+            cn = torch.zeros(m, dtype=torch.int64, device=self.device)
+            for r0 in range(0, n, rows):
+                cn += (_as_device_chunk(X, r0, min(n, r0 + rows), self.device) != 0).sum(0)
+            if reduce_fn is not None:
+                reduce_fn(cn)
+            self.set_col_order(cn)
         for r0 in range(0, n, rows):
             self.count_chunk(_as_device_chunk(X, r0, min(n, r0 + rows), self.device), r0)
         self.finish_count()
-        self.side_nz = None
         if side is not None:
-            self.side_nz = torch.empty(max(self.nnz, 1), dtype=torch.float32, device=self.device)
+            self.side_nz = torch.zeros(max(self.rslots, 1), dtype=torch.float32, device=self.device)
         for r0 in range(0, n, rows):
             r1 = min(n, r0 + rows)
             self.fill_chunk(_as_device_chunk(X, r0, r1, self.device), r0,
@@ -101,16 +161,23 @@ class CountTiles:
         return self.finish()
 
     @classmethod
-    def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda'):
-        """Two passes over `chunk_fn(r0, r1) -> dense device tensor` (deterministic generator)."""
+    def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda', sort_cols=True, reduce_fn=None):
+        """Passes over `chunk_fn(r0, r1) -> dense device tensor` (deterministic generator):
+        per-gene counts (when sort_cols), tile counts, fill."""
         assert chunk_rows % TILE == 0
         self = cls(n, m, device)
+        if sort_cols:
+            cn = torch.zeros(m, dtype=torch.int64, device=self.device)
+            for r0 in range(0, n, chunk_rows):
+                cn += (chunk_fn(r0, min(n, r0 + chunk_rows)) != 0).sum(0)
+            if reduce_fn is not None:
+                reduce_fn(cn)
+            self.set_col_order(cn)
         for r0 in range(0, n, chunk_rows):
             self.count_chunk(chunk_fn(r0, min(n, r0 + chunk_rows)).contiguous(), r0)
         self.finish_count()
         for r0 in range(0, n, chunk_rows):
             self.fill_chunk(chunk_fn(r0, min(n, r0 + chunk_rows)).contiguous(), r0)
-        self.side_nz = None
         return self.finish()
 
     @property
@@ -118,24 +185,44 @@ class CountTiles:
         return ctypes.byref(self._struct)
 
     def bytes_resident(self):
-        return (self.nnz * 9 + (self.nrb * self.ncb) * (2 * (TILE + 1) * 4 + 12))
+        return self.rslots * 8 + self.cslots + (self.nrb * self.ncb) * (2 * 17 * 4 + 2 * 8 + 4)
+
+    def slot_efficiency(self):
+        """(nnz / row-side slots, nnz / column-side slots): the share of lanes that carry a real entry."""
+        return (self.nnz / max(self.rslots, 1), self.nnz / max(self.cslots, 1))
 
     # ---- debugging / tests ------------------------------------------------------------------
+    _REC = np.dtype([('x', '<f4'), ('cdst', '<u2'), ('col', 'u1'), ('pad', 'u1')])
+
+    def host_arrays(self):
+        nt = self.nrb * self.ncb
+        return dict(roff=self.roff.cpu().numpy(), coff=self.coff.cpu().numpy(),
+                    rslice=self.rslice.cpu().numpy().view(np.uint32).reshape(-1, 17)[:max(nt, 1)],
+                    cslice=self.cslice.cpu().numpy().view(np.uint32).reshape(-1, 17)[:max(nt, 1)],
+                    rec=self.rowrec.cpu().numpy().view(self._REC), ridx=self.ridx.cpu().numpy())
+
     def to_dense(self):
         """Rebuild the dense float32 matrix on the host (tests only)."""
-        X = np.zeros((self.n, self.m), dtype=np.float32)
-        if self.nnz == 0:
-            return X
-        off = self.tile_off.cpu().numpy()
-        rp = self.row_ptr.cpu().numpy().view(np.uint32).reshape(-1, TILE + 1)
-        rec = self.rowrec[:self.nnz].cpu().numpy().view(np.dtype([('x', '<f4'), ('cpos', '<u2'), ('col', 'u1'), ('pad', 'u1')]))
-        for rb in range(self.nrb):
-            for cb in range(self.ncb):
-                t = rb * self.ncb + cb
-                for r in range(TILE):
-                    a, b = off[t] + rp[t, r], off[t] + rp[t, r + 1]
-                    if b > a:
-                        X[rb * TILE + r, cb * TILE + rec['col'][a:b].astype(np.int64)] = rec['x'][a:b]
+        X = np.zeros((self.nrb * TILE, self.ncb * TILE), dtype=np.float32)
+        if self.nnz:
+            h = self.host_arrays()
+            for rb in range(self.nrb):
+                for cb in range(self.ncb):
+                    t = rb * self.ncb + cb
+                    for sl in range(16):
+                        a, b = int(h['rslice'][t, sl]), int(h['rslice'][t, sl + 1])
+                        if b == a:
+                            continue
+                        seg = h['rec'][h['roff'][t] + a:h['roff'][t] + b]
+                        slot = np.arange(b - a)
+                        rows = rb * TILE + sl * 16 + ((slot & 63) >> 2)
+                        keep = seg['x'] != 0
+                        X[rows[keep], cb * TILE + seg['col'][keep].astype(np.int64)] = seg['x'][keep]
+        X = X[:self.n, :self.m]
+        if self.col_perm is not None:
+            out = np.zeros_like(X)
+            out[:, self.col_perm.cpu().numpy()] = X
+            X = out
         return X
 
 
@@ -146,14 +233,14 @@ class ZWorkspace:
         self.ct, self.K, self.Kp = ct, int(K), kpad(K)
         dev = ct.device
         f32 = dict(dtype=torch.float32, device=dev)
-        nnz1 = max(ct.nnz, 1)
         self.FU = torch.zeros(max(ct.n, 1), self.Kp, **f32)
         self.FV = torch.zeros(max(ct.m, 1), self.Kp, **f32)
         self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32)
         self.C = torch.zeros(max(ct.m, 1), self.Kp, **f32)
-        self.s_col = torch.empty(nnz1, **f32)
-        self.sw_col = torch.empty(nnz1, **f32) if need_sw else None
-        self.s_row = torch.empty(nnz1, **f32) if need_srow else None
+        # per-sweep scalars s_ij in column-side slots: padding slots must stay 0, hence zeros()
+        self.s_cs = torch.zeros(max(ct.cslots, 1), **f32)
+        self.sw_cs = torch.zeros(max(ct.cslots, 1), **f32) if need_sw else None
+        self.s_rs = torch.zeros(max(ct.rslots, 1), **f32) if need_srow else None
         self.tile_flag = torch.zeros(max(ct.nrb * ct.ncb, 1), dtype=torch.int32, device=dev)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
 
@@ -207,11 +294,16 @@ def _span(ws, name):
     return t.span(name) if t is not None else _NoSpan()
 
 
-def factor_prep(F, logF, mask=None, mu=None):
+def factor_prep(F, logF, mask=None, mu=None, row_index=None):
     r, K = logF.shape
     assert logF.dtype == torch.float32 and logF.is_contiguous()
-    call('oriana_factor_prep', ptr(F), ptr(mu), ptr(logF), ptr(mask), r, K, stream_ptr())
+    call('oriana_factor_prep', ptr(F), ptr(mu), ptr(logF), ptr(mask), ptr(row_index), r, K, stream_ptr())
     return F
+
+
+def col_pass(ct, s_cs, G, C, K):
+    w = ct.col_work
+    call('oriana_col_pass', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 
 def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat):
@@ -221,19 +313,19 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat):
     _check_f32(Z_hat_i, (ct.n, K)); _check_f32(Z_hat_j, (ct.m, K))
     _check_f32(log_U_hat, (ct.n, K)); _check_f32(log_V_hat, (ct.m, K))
     st = stream_ptr()
-    factor_prep(ws.FU, log_U_hat)
-    factor_prep(ws.FV, log_V_hat)
+    factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
+    factor_prep(ws.FV, log_V_hat, row_index=ct.col_perm)
     Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
     with _span(ws, 'row_pass'):
-        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, None, ptr(ws.R), ptr(ws.s_col), None, None,
+        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None, None,
              ptr(ws.tile_flag), K, st)
     with _span(ws, 'fixup'):
-        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_col), None, None, ptr(log_U_hat), ptr(log_V_hat),
+        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat), ptr(log_V_hat),
              None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
     with _span(ws, 'col_pass'):
-        call('oriana_col_pass', ct.c_struct, ptr(ws.s_col), ptr(ws.FU), ptr(ws.C), K, st)
-    call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ct.n, K, 1, st)
-    call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ct.m, K, 1, st)
+        col_pass(ct, ws.s_cs, ws.FU, ws.C, K)
+    call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), ct.n, K, 1, st)
+    call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
 
 
 def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):

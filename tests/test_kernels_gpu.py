@@ -36,27 +36,36 @@ def test_pack_roundtrip(eng, n, m, density, dtype):
     ct = eng.CountTiles.from_dense(X, 'cuda')
     assert ct.nnz == int((X != 0).sum())
     assert np.array_equal(ct.to_dense(), X.astype(np.float32))
-    # column-major structures: ridx / cpos consistent with the row-major records
+    # column-side structures are consistent with the row-side records
     if ct.nnz:
-        T = 256
-        off = ct.tile_off.cpu().numpy()
-        rp = ct.row_ptr.cpu().numpy().view(np.uint32).reshape(-1, T + 1)
-        cp = ct.col_ptr.cpu().numpy().view(np.uint32).reshape(-1, T + 1)
-        rec = ct.rowrec[:ct.nnz].cpu().numpy().view(np.dtype([('x', '<f4'), ('cpos', '<u2'), ('col', 'u1'), ('pad', 'u1')]))
-        ridx = ct.ridx[:ct.nnz].cpu().numpy()
+        h = ct.host_arrays()
+        Xp = X.astype(np.float32)
+        if ct.col_perm is not None:
+            Xp = Xp[:, ct.col_perm.cpu().numpy()]
+        seen_total = 0
         for t in range(ct.nrb * ct.ncb):
-            cnt = off[t + 1] - off[t]
-            assert rp[t, T] == cnt and cp[t, T] == cnt
-            seen = np.zeros(cnt, dtype=bool)
-            for r in range(T):
-                for p in range(rp[t, r], rp[t, r + 1]):
-                    e = rec[off[t] + p]
-                    c = int(e['col']); q = int(e['cpos'])
-                    assert cp[t, c] <= q < cp[t, c + 1]
-                    assert ridx[off[t] + q] == r
-                    assert not seen[q]
-                    seen[q] = True
-            assert seen.all()
+            rb, cb = divmod(t, ct.ncb)
+            rs, cs = h['rslice'][t], h['cslice'][t]
+            assert h['roff'][t + 1] - h['roff'][t] == rs[16]
+            assert h['coff'][t + 1] - h['coff'][t] == cs[16] + 64          # + dummy slots
+            assert (rs % 64 == 0).all() and (cs % 64 == 0).all()
+            rec = h['rec'][h['roff'][t]:h['roff'][t + 1]]
+            rid = h['ridx'][h['coff'][t]:h['coff'][t + 1]]
+            slot = np.arange(len(rec))
+            sl = np.searchsorted(rs, slot, side='right') - 1
+            row = sl * 16 + (((slot - rs[sl]) & 63) >> 2)
+            keep = rec['x'] != 0
+            seen_total += int(keep.sum())
+            cd = rec['cdst'][keep].astype(np.int64)
+            assert len(np.unique(cd)) == len(cd) and (cd < cs[16]).all()
+            # the column-side slot of an entry belongs to the entry's column and names its row
+            csl = np.searchsorted(cs, cd, side='right') - 1
+            colc = csl * 16 + (((cd - cs[csl]) & 63) >> 2)
+            assert np.array_equal(colc, rec['col'][keep].astype(np.int64))
+            assert np.array_equal(rid[cd].astype(np.int64), row[keep])
+            gr = rb * 256 + row[keep]; gc = cb * 256 + rec['col'][keep].astype(np.int64)
+            assert np.array_equal(Xp[gr, gc], rec['x'][keep])
+        assert seen_total == ct.nnz
 
 
 def _same_zeros(got, ref):

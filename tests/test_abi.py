@@ -49,10 +49,10 @@ def test_kpad_and_version(lib):
 def test_argument_errors_without_gpu(lib):
     """Argument validation happens before any HIP call: usable on a CPU-only host."""
     lib.oriana_factor_prep.restype = ctypes.c_int
-    lib.oriana_factor_prep.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 2 + [ctypes.c_void_p]
-    assert lib.oriana_factor_prep(None, None, None, None, -1, 3, None) == -1       # ORIANA_EINVAL
-    assert lib.oriana_factor_prep(None, None, None, None, 4, 1000, None) == -2     # ORIANA_EKRANGE
-    assert lib.oriana_factor_prep(None, None, None, None, 0, 3, None) == 0         # empty input is fine
+    lib.oriana_factor_prep.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_void_p]
+    assert lib.oriana_factor_prep(None, None, None, None, None, -1, 3, None) == -1       # ORIANA_EINVAL
+    assert lib.oriana_factor_prep(None, None, None, None, None, 4, 1000, None) == -2     # ORIANA_EKRANGE
+    assert lib.oriana_factor_prep(None, None, None, None, None, 0, 3, None) == 0         # empty input is fine
 
 
 def test_missing_library_fails_loudly(monkeypatch):

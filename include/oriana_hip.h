@@ -206,6 +206,46 @@ int oriana_mstep_gamma(double *p1, double *p2, const double *colsum_E, const dou
  * into out[K] (zero it first) -- `V_hat.sum(axis=0)`, gap.py:98. */
 int oriana_colsum_f64(double *out, const double *A, const float *mul, int64_t r, int64_t K, void *stream);
 
+/* ---- zero-inflated / sparse model pieces -------------------------------------------------------
+ * D_q update (zigap.py:130-136, sparse_zigap.py:163-169), in three steps:
+ *   oriana_dropout_update : p_d = sigmoid(logit(pi_d)[None, :] - Lambda), columns with pi_d <= 0 -> 1e-10,
+ *                           pi_d >= 1 -> 1 - 1e-10; D_hat = float32(p_d).  Lambda = U_hat V_hat^T, dense
+ *                           (rows, m) f64, may alias p_d.
+ *   oriana_dropout_fix_nz : p_d[X != 0] = value (1 - 1e-10; 1.0 at initialisation, zigap.py:77) and D_hat,
+ *                           from the tiled layout.
+ *   oriana_colsum_wide_f64: out[j] += sum_i A[i, j]  (pi_d = mean(p_d, axis=0), zigap.py:158).
+ */
+int oriana_dropout_update(double *p_d, float *D_hat, const double *Lambda, const double *pi_d,
+                          int64_t rows, int64_t m, void *stream);
+int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
+int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);
+/* dq[i, k] = D[i, k], k < K: the columns the reference's zigap.py:94 reads (D_hat[i, k]). */
+int oriana_take_cols_f32(float *out, const float *D, int64_t rows, int64_t m, int64_t K, void *stream);
+
+/* S_q update (sparse_gap.py:134-141, sparse_zigap.py:154-161):
+ *   p_s = nan_to_num(sigmoid(logit(pi_s)[:, None] - (-Zlog + nan_to_num(c * Vprime_hat)))),
+ *   c = c_vec[k] (sum_i U_hat) or c_mat[j, k] (D_hat^T U_hat); rows with pi_s <= 0 / >= 1 overridden;
+ *   S_hat = float32(p_s).  oriana_threshold_f32: S_tilde = (p_s > tau) (sparse_gap.py:113).
+ *   oriana_rowmean_f64: pi_s = mean(p_s, axis=1) (sparse_gap.py:165). */
+int oriana_sparsity_update(double *p_s, float *S_hat, const double *pi_s, const float *Zlog,
+                           const double *c_vec, const double *c_mat, const double *Vprime_hat,
+                           int64_t m, int64_t K, void *stream);
+int oriana_threshold_f32(float *out, const double *p, double tau, int64_t len, void *stream);
+int oriana_rowmean_f64(double *out, const double *A, int64_t r, int64_t K, void *stream);
+
+/* out = A * B element-wise, f64 x f32 -> f64 (V_hat = S_hat * Vprime_hat, sparse_gap.py:118). */
+int oriana_mul_f64_f32(double *out, const double *A, const float *B, int64_t len, void *stream);
+
+/* Fout[i, :] = Fin[i, :] * mul[row_index ? row_index[i] : i, :]  (padded factor times a dense (., K) f32
+ * matrix: S_hat-, D_hat[:, :K]- or E[log U]-weighted factors for the extra sums of the ZI / sparse loop
+ * nests).  zero_guard: entries with Fin == 0 stay 0 whatever mul holds. */
+int oriana_scale_factor(float *Fout, const float *Fin, const float *mul, const int32_t *row_index,
+                        int64_t r, int64_t K, int zero_guard, void *stream);
+/* Zlog[o, k] += FV[j, k] * (C2[j, k] + logV[o, k] * C[j, k]), o = row_index ? row_index[j] : j
+ * (sum_i r_ijk (lu_ik + lv_jk), zigap.py:95, split into its two column sums). */
+int oriana_finalize_zlog(float *Zlog, const float *FV, const float *C2, const float *C, const float *logV,
+                         const int32_t *row_index, int64_t r, int64_t K, void *stream);
+
 /* Element-wise special functions on f64 vectors (oriana/utils.py:9-15, 31-51) -- used by tests
  * and by the host mirror of oriana.utils. */
 int oriana_digamma_f64(double *y, const double *x, int64_t len, void *stream);

@@ -260,6 +260,8 @@ class _OracleModel:
             zq_sparse_zigap(Zi, Zj, Zlog, self.log_U_hat, self.log_V_hat, S_tilde,
                             self.S_hat, self.D_hat, self.Xf)                      # sparse_zigap.py:126-135
         self.last_Z = (Zi, Zj, Zlog)
+        if self.zi:
+            self.last_D_hat = self.D_hat        # the D_hat this sweep's sums used (tests: conditioning)
 
         with np.errstate(all='ignore'):
             # -- U_q (gap.py:96-102, zigap.py:114-120, sparse_gap.py:117-124, sparse_zigap.py:137-144)

@@ -43,6 +43,16 @@ _SIGS = {
     'oriana_gamma_update': (c_int, [_P] * 13 + [_I, _I, _P]),
     'oriana_mstep_gamma': (c_int, [_P, _P, _P, _P, c_double, _I, _P]),
     'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),
+    'oriana_dropout_update': (c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    'oriana_dropout_fix_nz': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, c_double, _P]),
+    'oriana_mul_f64_f32': (c_int, [_P, _P, _P, _I, _P]),
+    'oriana_colsum_wide_f64': (c_int, [_P, _P, _I, _I, _P]),
+    'oriana_take_cols_f32': (c_int, [_P, _P, _I, _I, _I, _P]),
+    'oriana_sparsity_update': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_threshold_f32': (c_int, [_P, _P, c_double, _I, _P]),
+    'oriana_rowmean_f64': (c_int, [_P, _P, _I, _I, _P]),
+    'oriana_scale_factor': (c_int, [_P, _P, _P, _P, _I, _I, c_int, _P]),
+    'oriana_finalize_zlog': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_digamma_f64': (c_int, [_P, _P, _I, _P]),
     'oriana_trigamma_f64': (c_int, [_P, _P, _I, _P]),
     'oriana_inverse_digamma_f64': (c_int, [_P, _P, _I, _P]),

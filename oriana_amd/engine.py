@@ -243,6 +243,15 @@ class ZWorkspace:
         self.s_rs = torch.zeros(max(ct.rslots, 1), **f32) if need_srow else None
         self.tile_flag = torch.zeros(max(ct.nrb * ct.ncb, 1), dtype=torch.int32, device=dev)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
+        self._extra = {}
+
+    def extra(self, name, rows):
+        """Lazily allocated padded (rows, Kp) scratch factor / accumulator matrices."""
+        t = self._extra.get(name)
+        if t is None:
+            t = torch.zeros(max(rows, 1), self.Kp, dtype=torch.float32, device=self.ct.device)
+            self._extra[name] = t
+        return t
 
 
 class KernelTimer:
@@ -343,6 +352,61 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
     base = (ws.data_ptr() + 255) // 256 * 256
     call('oriana_zq_gap_f32', ptr(Z_hat_i), ptr(Z_hat_j), ptr(log_U_hat), ptr(log_V_hat), ptr(X), n, m, K,
          base, nbytes, stream_ptr())
+
+
+def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None):
+    """The four loop nests on the resident tiles, for entries whose dropout posterior is 1 at the
+    non-zero counts (always the case inside the models, zigap.py:135):
+      Z_i[i,k]   = sum_j [S_hat[j,k]] r_ijk                    (gap.py:79, sparse_gap.py:95)
+      Z_j[j,k]   = sum_i [dq[i,k]] r_ijk                       (gap.py:80; dq = D_hat[:, :K], zigap.py:94)
+      Z_log[j,k] = sum_i r_ijk (lu_ik + lv_jk)                 (zigap.py:95) -- skipped when Z_log is None
+    with r_ijk = x_ij e_k / sum_k e_k, e_k = exp(lu_ik + lv_jk) [S_tilde[j,k]].  Outputs first,
+    zero-filled here, float32 device tensors."""
+    ct, K = ws.ct, ws.K
+    n, m = ct.n, ct.m
+    _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
+    sparse = S_hat is not None
+    if sparse and ws.s_rs is None:
+        ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
+    st = stream_ptr()
+    factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
+    factor_prep(ws.FV, log_V_hat, mask=S_tilde, row_index=ct.col_perm)
+    Z_i.zero_(); Z_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
+    if Z_log is not None:
+        Z_log.zero_()
+    with _span(ws, 'row_pass'):
+        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None,
+             ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
+    with _span(ws, 'fixup'):
+        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, ptr(ws.s_rs) if sparse else None,
+             ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), None, ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
+             K, (1 if sparse else 0) | (4 if dq is not None else 0), st)
+    R = ws.R
+    if sparse:
+        F2 = ws.extra('FVS', m)
+        call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
+        with _span(ws, 'row_spmm'):
+            call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), None, ptr(F2), ptr(ws.R), K, st)
+    call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(R), None, ptr(ct.row_perm), n, K, 1, st)
+    G = ws.FU
+    if dq is not None:
+        G = ws.extra('GQ', n)
+        call('oriana_scale_factor', ptr(G), ptr(ws.FU), ptr(dq), ptr(ct.row_perm), n, K, 0, st)
+    with _span(ws, 'col_pass'):
+        col_pass(ct, ws.s_cs, G, ws.C, K)
+    call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
+    if Z_log is not None:
+        _check_f32(Z_log, (m, K))
+        if dq is not None:                      # the log sums use the un-weighted column sums
+            ws.C.zero_()
+            col_pass(ct, ws.s_cs, ws.FU, ws.C, K)
+        G2 = ws.extra('GL', n)
+        C2 = ws.extra('C2', m)
+        C2.zero_()
+        call('oriana_scale_factor', ptr(G2), ptr(ws.FU), ptr(log_U_hat), ptr(ct.row_perm), n, K, 1, st)
+        with _span(ws, 'col_pass_log'):
+            col_pass(ct, ws.s_cs, G2, C2, K)
+        call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ptr(ct.col_perm), m, K, st)
 
 
 def _check_f32(t, shape):

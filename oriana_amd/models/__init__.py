@@ -1,2 +1,3 @@
 from .base import *     # noqa: F401,F403
 from .gap import *      # noqa: F401,F403
+from .zigap import *    # noqa: F401,F403

@@ -226,6 +226,8 @@ class FactorModel:
             if hasattr(self, k):
                 out[k] = getattr(self, k).asarray()
         out.update(U_hat=self.U_hat, V_hat=self.V_hat, log_U_hat=self.log_U_hat, log_V_hat=self.log_V_hat)
+        if hasattr(self, '_S_hat'):
+            out['S_hat'] = self.S_hat
         return out
 
     def load_state(self, st):

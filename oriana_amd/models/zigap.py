@@ -1,0 +1,248 @@
+# -*- coding: utf-8 -*-
+"""Zero-inflated and sparse variants (reference oriana/models/zigap.py:15-165,
+sparse_gap.py:15-172, sparse_zigap.py:15-204) on the HIP path.
+
+The responsibility sums run on the resident non-zero tiles (engine.zq); the dropout posterior is
+exactly 1 (in float32) at every non-zero count -- zigap.py:135 sets p_d[X != 0] = 1 - 1e-10 and
+Bernoulli.mean casts to float32 (bernoulli.py:45) -- so the loop nests never need D_hat[i, j] at
+the non-zeros.  The three dense contractions of the ZI models (D_hat V_hat, D_hat^T U_hat,
+U_hat V_hat^T: zigap.py:116, 124, 132) are plain float64 GEMMs and go through rocBLAS
+(torch.matmul); everything around them is in the element-wise kernels of csrc/dense.hip.
+"""
+import numpy as np
+import torch
+
+from .. import engine
+from .. import dist as odist
+from .._lib import call, ptr, stream_ptr
+from ..parameters import Parameter
+from .base import FactorModel
+
+__all__ = ['ZIGaP', 'SparseGaP', 'SparseZIGaP']
+
+_ROW_CHUNK_BYTES = 2 << 30
+
+
+class _ZIMixin:
+    """Dropout node D (zigap.py:31-43, 76-77, 130-136, 157-158)."""
+
+    def _init_zi(self):
+        n, m, dev = self.n, self.m, self.device
+        self.pi_d = Parameter(torch.zeros(m, dtype=torch.float64, device=dev))
+        # p_d = (X > 0) as float (zigap.py:77): exactly 1.0 at the non-zero counts
+        p_d = torch.zeros(n, m, dtype=torch.float64, device=dev)
+        self._D_hat = torch.zeros(n, m, dtype=torch.float32, device=dev)
+        call('oriana_dropout_fix_nz', self.counts.c_struct, ptr(p_d), ptr(self._D_hat), 1.0, stream_ptr())
+        self.p_d = Parameter(p_d)
+        self._pd_sum = torch.zeros(m, dtype=torch.float64, device=dev)
+
+    @property
+    def D_hat(self):
+        return self._D_hat.cpu().numpy()
+
+    def _refresh_D_hat(self):
+        self._D_hat.copy_(self.p_d.tensor)              # Bernoulli.mean: float32 cast (bernoulli.py:45)
+
+    def _mstep_pi_d(self):
+        """pi_d = mean(p_d, axis=0) (zigap.py:158), summed over the row shards."""
+        self._pd_sum.zero_()
+        call('oriana_colsum_wide_f64', ptr(self._pd_sum), ptr(self.p_d.tensor), self.n, self.m, stream_ptr())
+        odist.all_reduce_sum(self._pd_sum, self.pg)
+        torch.div(self._pd_sum, float(self.n_total), out=self.pi_d.tensor)
+
+    def _rows_per_chunk(self):
+        return max(256, int(_ROW_CHUNK_BYTES // max(1, self.m * 8)))
+
+    def _D_times(self, V):
+        """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K)."""
+        out = torch.empty(self.n, self.k, dtype=torch.float64, device=self.device)
+        step = self._rows_per_chunk()
+        for r0 in range(0, self.n, step):
+            torch.matmul(self._D_hat[r0:r0 + step].double(), V, out=out[r0:r0 + step])
+        return out
+
+    def _Dt_times(self, U):
+        """np.dot(D_hat.T, U) (zigap.py:124), summed over the row shards.  (m, K)."""
+        out = torch.zeros(self.m, self.k, dtype=torch.float64, device=self.device)
+        step = self._rows_per_chunk()
+        for r0 in range(0, self.n, step):
+            out.addmm_(self._D_hat[r0:r0 + step].double().t(), U[r0:r0 + step])
+        return odist.all_reduce_sum(out, self.pg)
+
+    def _update_D(self, V_for_d):
+        """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat."""
+        st = stream_ptr()
+        torch.matmul(self._U_hat, V_for_d.t(), out=self.p_d.tensor)        # Lambda, written into the p_d buffer
+        call('oriana_dropout_update', ptr(self.p_d.tensor), ptr(self._D_hat), ptr(self.p_d.tensor),
+             ptr(self.pi_d.tensor), self.n, self.m, st)
+        call('oriana_dropout_fix_nz', self.counts.c_struct, ptr(self.p_d.tensor), ptr(self._D_hat), 1.0 - 1e-10, st)
+
+
+class _SparseMixin:
+    """Sparsity node S on V (sparse_gap.py:26-34, 79, 113, 134-141, 164-165)."""
+
+    def _init_sparse(self):
+        m, K, dev = self.m, self.k, self.device
+        self.pi_s = Parameter(torch.zeros(m, dtype=torch.float64, device=dev))
+        self.p_s = Parameter(torch.ones(m, K, dtype=torch.float64, device=dev))       # sparse_gap.py:79
+        self._S_hat = torch.ones(m, K, dtype=torch.float32, device=dev)
+        self._S_tilde = torch.ones(m, K, dtype=torch.float32, device=dev)
+        self._Zlog = torch.zeros(max(m, 1), K, dtype=torch.float32, device=dev)
+        self._Veff = torch.zeros(m, K, dtype=torch.float64, device=dev)
+        self._sumVeff = torch.zeros(K, dtype=torch.float64, device=dev)
+
+    @property
+    def S_hat(self):
+        return self._S_hat.cpu().numpy()
+
+    # the Gamma node of the sparse models is Vprime (sparse_gap.py:31): same buffers, reference names
+    @property
+    def Vprime_hat(self):
+        return self.V_hat
+
+    @property
+    def log_Vprime_hat(self):
+        return self.log_V_hat
+
+    def _effective_V(self):
+        self._compute_Veff()
+        return self._Veff
+
+    def _compute_Veff(self):
+        """V_hat = S_hat * Vprime_hat (sparse_gap.py:118)."""
+        call('oriana_mul_f64_f32', ptr(self._Veff), ptr(self._V_hat), ptr(self._S_hat), self.m * self.k, stream_ptr())
+
+    def _refresh_S_hat(self):
+        self._S_hat.copy_(self.p_s.tensor)
+
+    def _mstep_pi_s(self):
+        call('oriana_rowmean_f64', ptr(self.pi_s.tensor), ptr(self.p_s.tensor), self.m, self.k, stream_ptr())
+
+    def _update_S(self, c_vec=None, c_mat=None):
+        """sparse_gap.py:134-141 (uses the NEW Vprime_hat and the sums of the NEW U_hat)."""
+        call('oriana_sparsity_update', ptr(self.p_s.tensor), ptr(self._S_hat), ptr(self.pi_s.tensor), ptr(self._Zlog),
+             ptr(c_vec), ptr(c_mat), ptr(self._V_hat), self.m, self.k, stream_ptr())
+
+
+class ZIGaP(_ZIMixin, FactorModel):
+    """ZI-pCMF (reference zigap.py:15-165)."""
+    zi = True
+
+    def _init_extra(self):
+        self._init_zi()
+
+    def update_expectations(self):
+        FactorModel.update_expectations(self)
+        self._refresh_D_hat()
+
+    def update_prior_hyper_parameters(self):
+        FactorModel.update_prior_hyper_parameters(self)
+        self._mstep_pi_d()
+
+    def update_variational_parameters(self):
+        """zigap.py:97-141."""
+        dq = None
+        if self.reference_quirks:
+            # zigap.py:94 weights the per-gene sums with D_hat[i, k] (first K gene columns)
+            dq = torch.empty(self.n, self.k, dtype=torch.float32, device=self.device)
+            call('oriana_take_cols_f32', ptr(dq), ptr(self._D_hat), self.n, self.m, self.k, stream_ptr())
+        engine.zq(self._ws, self._Zi, self._Zj, None, self._log_U_hat, self._log_V_hat, dq=dq)
+        # U_q: a2 = alpha2 + D_hat V_hat (OLD V_hat)                                  zigap.py:115-120
+        self._gamma_side('u', self._Zi, rate_mat=self._D_times(self._V_hat))
+        odist.all_reduce_sum(self._Zj, self.pg)
+        odist.all_reduce_sum(self._sumU, self.pg)
+        # V_q: b2 = beta2 + D_hat^T U_hat (NEW U_hat)                                 zigap.py:123-128
+        self._gamma_side('v', self._Zj, rate_mat=self._Dt_times(self._U_hat))
+        # D_q (NEW U_hat, NEW V_hat)                                                  zigap.py:130-136
+        self._update_D(self._V_hat)
+
+    def _load_extra(self, st):
+        if 'p_d' in st:
+            self._refresh_D_hat()
+
+
+class SparseGaP(_SparseMixin, FactorModel):
+    """Sparse pCMF (reference sparse_gap.py:15-172; the NameError of sparse_gap.py:127 -- a bare
+    `S_hat` -- is read as the evident self.S_hat, SURVEY.md 8(a) policy)."""
+    sparse = True
+
+    def _init_extra(self):
+        self._init_sparse()
+
+    def update_expectations(self):
+        FactorModel.update_expectations(self)
+        self._refresh_S_hat()
+
+    def update_prior_hyper_parameters(self):
+        FactorModel.update_prior_hyper_parameters(self)
+        self._mstep_pi_s()
+
+    def _threshold(self):
+        call('oriana_threshold_f32', ptr(self._S_tilde), ptr(self.p_s.tensor), float(self.tau), self.m * self.k, stream_ptr())
+
+    def update_variational_parameters(self):
+        """sparse_gap.py:99-148."""
+        self._threshold()                                                              # sparse_gap.py:113
+        engine.zq(self._ws, self._Zi, self._Zj, self._Zlog, self._log_U_hat, self._log_V_hat,
+                  S_tilde=self._S_tilde, S_hat=self._S_hat)
+        # U_q: a2 = alpha2 + sum_j S_hat * Vprime_hat (OLD)                            sparse_gap.py:118-124
+        self._sumVeff.zero_()
+        call('oriana_colsum_f64', ptr(self._sumVeff), ptr(self._V_hat), ptr(self._S_hat), self.m, self.k, stream_ptr())
+        self._gamma_side('u', self._Zi, rate_vec=self._sumVeff)
+        odist.all_reduce_sum(self._Zj, self.pg)
+        odist.all_reduce_sum(self._Zlog, self.pg)
+        odist.all_reduce_sum(self._sumU, self.pg)
+        # Vprime_q: b1 = beta1 + S_hat * Z_j ; b2 = beta2 + S_hat * sum_i U_hat (NEW)  sparse_gap.py:127-132
+        self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_vec=self._sumU[0], rmul=self._S_hat)
+        # S_q                                                                          sparse_gap.py:134-141
+        self._update_S(c_vec=self._sumU[0])
+
+    def _load_extra(self, st):
+        if 'p_s' in st:
+            self._refresh_S_hat()
+
+
+class SparseZIGaP(_ZIMixin, _SparseMixin, FactorModel):
+    """Sparse ZI-pCMF (reference sparse_zigap.py:15-204)."""
+    zi = True
+    sparse = True
+
+    def _init_extra(self):
+        self._init_zi()
+        self._init_sparse()
+
+    def update_expectations(self):
+        FactorModel.update_expectations(self)
+        self._refresh_D_hat()
+        self._refresh_S_hat()
+
+    def update_prior_hyper_parameters(self):
+        FactorModel.update_prior_hyper_parameters(self)
+        self._mstep_pi_d()                                                             # sparse_zigap.py:193
+        self._mstep_pi_s()                                                             # sparse_zigap.py:196
+
+    _threshold = SparseGaP._threshold
+
+    def update_variational_parameters(self):
+        """sparse_zigap.py:118-176."""
+        self._threshold()
+        engine.zq(self._ws, self._Zi, self._Zj, self._Zlog, self._log_U_hat, self._log_V_hat,
+                  S_tilde=self._S_tilde, S_hat=self._S_hat)
+        # V_hat = S_hat * Vprime_hat, computed BEFORE the updates and used again by the D update
+        # (sparse_zigap.py:138, 165)
+        self._compute_Veff()
+        V_old = self._Veff.clone()
+        self._gamma_side('u', self._Zi, rate_mat=self._D_times(V_old))                 # sparse_zigap.py:139-144
+        odist.all_reduce_sum(self._Zj, self.pg)
+        odist.all_reduce_sum(self._Zlog, self.pg)
+        odist.all_reduce_sum(self._sumU, self.pg)
+        DtU = self._Dt_times(self._U_hat)                                               # NEW U_hat, OLD D_hat
+        self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_mat=DtU, rmul=self._S_hat)   # :147-152
+        self._update_S(c_mat=DtU)                                                       # :154-161
+        self._update_D(V_old)                                                           # :163-169
+
+    def _load_extra(self, st):
+        if 'p_d' in st:
+            self._refresh_D_hat()
+        if 'p_s' in st:
+            self._refresh_S_hat()

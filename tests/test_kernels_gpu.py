@@ -176,3 +176,76 @@ def test_stateless_dropin_signature(eng):
     Z0 = torch.zeros_like(X)
     GaP.compute_Z_q_expectations(Zi, Zj, lu, lv, Z0)
     assert not Zi.any() and not Zj.any()
+
+
+def _variant_inputs(g):
+    s0 = {k[3:]: v for k, v in g.items() if k.startswith('s0/')}
+    name = str(g['meta/name'])
+    out = dict(lu=s0['log_U_hat'], lv=s0['log_V_hat'], D=None, St=None, Sh=None)
+    if 'p_d' in s0:
+        out['D'] = s0['p_d'].astype(np.float32)
+    if 'p_s' in s0:
+        out['St'] = (s0['p_s'] > float(g['meta/tau'])).astype(np.float32)
+        out['Sh'] = s0['p_s'].astype(np.float32)
+    return name, out
+
+
+@pytest.mark.parametrize('path', golden_files('zigap_*.npz') + golden_files('sparse*.npz'), ids=os.path.basename)
+def test_zq_variants_golden(eng, path):
+    """ZIGaP / SparseGaP / SparseZIGaP loop nests (zigap.py:79-95, sparse_gap.py:81-97,
+    sparse_zigap.py:100-116) against the reference's own outputs on the post-init state."""
+    g = load_golden(path)
+    name, a = _variant_inputs(g)
+    X = g['X']; n, m = X.shape; K = a['lu'].shape[1]
+    if a['D'] is not None:
+        assert (a['D'][X != 0] == 1.0).all()          # what the model path relies on (zigap.py:135)
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    ws = eng.ZWorkspace(ct, K)
+    dev = lambda v: None if v is None else torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda'); Zl = torch.empty(m, K, device='cuda')
+    dq = dev(a['D'][:, :K]) if name == 'ZIGaP' else None      # zigap.py:94 reads D_hat[i, k]
+    eng.zq(ws, Zi, Zj, Zl, dev(a['lu']), dev(a['lv']), S_tilde=dev(a['St']), S_hat=dev(a['Sh']), dq=dq)
+    torch.cuda.synchronize()
+    assert err_colrel(Zi.cpu().numpy(), g['kernel/Zi']) < RTOL
+    assert err_colrel(Zj.cpu().numpy(), g['kernel/Zj']) < RTOL
+    assert err_colrel(Zl.cpu().numpy(), g['kernel/Zlog']) < RTOL
+    assert np.isfinite(Zl.cpu().numpy()).all()
+
+
+def test_zq_zigap_without_quirk(eng):
+    """reference_quirks=False: the evident D_hat[i, j] in zigap.py:94 (oracle quirk=False)."""
+    from oracle import cavi_oracle as co
+    g = load_golden(golden_files('zigap_odd_rand.npz')[0])
+    name, a = _variant_inputs(g)
+    X = g['X']; n, m = X.shape; K = a['lu'].shape[1]
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    ws = eng.ZWorkspace(ct, K)
+    Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda'); Zl = torch.empty(m, K, device='cuda')
+    eng.zq(ws, Zi, Zj, Zl, torch.from_numpy(a['lu']).cuda(), torch.from_numpy(a['lv']).cuda())
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_zigap(r[0], r[1], r[2], a['lu'], a['lv'], a['D'], np.ascontiguousarray(X.astype(np.float32)), quirk=False)
+    for got, ref in zip((Zi, Zj, Zl), r):
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL
+
+
+@pytest.mark.parametrize('K', [7, 100, 200])
+def test_zq_sparse_random(eng, K):
+    """Sparse loop nest on random inputs with inactive factors (S_tilde zeros), several tiles."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(K)
+    n, m = 300, 520
+    X = _rand_counts(rng, n, m, 0.1)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    ps = rng.random((m, K))
+    St = (ps > 0.3).astype(np.float32); Sh = ps.astype(np.float32)
+    St[5] = 0                                   # a gene with every factor switched off: den == 0 guard
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    ws = eng.ZWorkspace(ct, K)
+    Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda'); Zl = torch.empty(m, K, device='cuda')
+    c = lambda v: torch.from_numpy(v).cuda()
+    eng.zq(ws, Zi, Zj, Zl, c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh))
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_sparse_gap(r[0], r[1], r[2], lu, lv, St, Sh, np.ascontiguousarray(X.astype(np.float32)))
+    for got, ref in zip((Zi, Zj, Zl), r):
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL
+    assert not Zj.cpu().numpy()[5].any()

@@ -62,11 +62,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs a torch.distributed launch (WORLD_SIZE=%d)' % (args.gpus, world))
+    # ORIANA_BENCH_ONE_GPU=1 (self-test on a 1-GPU box): every rank uses cuda:0 and gloo replaces RCCL
+    one_gpu = os.environ.get('ORIANA_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from oriana_amd import engine, dist as odist
     from oriana_amd.models import GaP
@@ -78,7 +85,8 @@ def main():
     seed = 1234 + 1000 * 4
     t_setup = time.time()
     gen = SyntheticCounts(n_total, m, K, seed=seed, device=dev, zero_inflation_level=z, row0=r0, n=n)
-    counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev)
+    counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
+                                           reduce_fn=(lambda t: odist.all_reduce_sum(t)) if world > 1 else None)
     a1, b1 = gen.initial_shapes()
     model = GaP(counts, k=K, use_factors=False, init=(a1, b1), device=dev,
                 process_group=(dist.group.WORLD if world > 1 else None), n_total=n_total)

@@ -108,7 +108,10 @@ template <int U> __device__ __forceinline__ uint32_t qb_u32(uint32_t v) { return
 template <int U> __device__ __forceinline__ float qb_f32(float v) { return quad_bcast_f32<U>(v); }
 
 // stage `rows` factor rows starting at global row j0 (bounded by jmax) into an LDS image
-template <int KP4, int STRIDE4>
+// With a tail (TAILREP > 1) the last float4 of a row is replicated TAILREP times behind the row:
+// the quads of a wave read their tail float from different copies, i.e. from different LDS banks
+// (rows are 512 bytes apart, so without this every quad of a ds_read_b32 would hit the same 4 banks).
+template <int KP4, int STRIDE4, int TAILREP = 1>
 __device__ __forceinline__ void stage_rows(f4 *img, const float *__restrict__ F, int64_t j0, int64_t jmax,
                                            int rows, int tid) {
 #ifdef ORIANA_ABLATE_NOSTAGE
@@ -120,12 +123,28 @@ __device__ __forceinline__ void stage_rows(f4 *img, const float *__restrict__ F,
         // rows past the end are zero-filled: padding slots point at image row 0 and must read finite values
         img[jr * STRIDE4 + c4] = (j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + c4] : f4{0.f, 0.f, 0.f, 0.f};
     }
+    if (TAILREP > 1) {
+        // the extra copies of the tail float4: one store per thread and copy, all lanes busy
+        for (int idx = tid; idx < rows * (TAILREP - 1); idx += 1024) {
+            const int jr = idx / (TAILREP - 1), rep = idx - jr * (TAILREP - 1) + 1;
+            const int64_t j = j0 + jr;
+            img[jr * STRIDE4 + (KP4 - 1) + rep] =
+                (j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + (KP4 - 1)] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 }
 
 // Geometry of a wave inside the 1024-thread workgroup.
 //   RW  = rows (columns) owned by one wave = 64 / G
 //   a 16-row slice is shared by WPS = 16 / RW waves; wave `w` handles sub-slice h = w % WPS
 //   the workgroup covers 16 * RW rows = SPLIT-th part of the 256-row block
+// copies of the tail that fit behind a row of KP floats inside its 256-byte aligned stride
+constexpr int tail_copies(int KP, int TAIL) {
+    if (!TAIL) return 1;
+    int free4 = (lds_stride_floats(KP) - KP) / 4 + 1;      // float4 slots from the tail to the end of the stride
+    return free4 > 8 ? 8 : free4;
+}
+
 template <int G>
 struct WaveGeo {
     static constexpr int RW = 64 / G;
@@ -138,7 +157,7 @@ struct WaveGeo {
 // row pass:  s = x / <FU_i, FV_j>,   R_i += w s FV_j
 //   VAR bit 0: also write s in row-side slots (s_rs);  bit 1: per-entry weights w_nz / sw_cs
 // ------------------------------------------------------------------------------------------
-template <int G, int T4, int VAR>
+template <int G, int T4, int TAIL, int VAR>
 __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float *__restrict__ FU,
                                                    const float *__restrict__ FV, const float *__restrict__ w_nz,
                                                    float *__restrict__ R, float *__restrict__ s_cs,
@@ -146,7 +165,9 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                                                    int32_t *__restrict__ tile_flag) {
     constexpr bool SROW = (VAR & 1) != 0, HASW = (VAR & 2) != 0;
     constexpr int PD = HASW ? 2 : 3;            // prefetch depth (iterations), bounded by the register budget
-    constexpr int KP = 4 * G * T4;
+    constexpr int KP = 4 * G * T4 + G * TAIL;   // TAIL: one extra float per lane after the float4 chunks
+    constexpr int TOFF = 4 * G * T4;            // float offset of the tail inside a row
+    constexpr int TREP = (G == 4) ? tail_copies(KP, TAIL) : 1;
     constexpr int KP4 = KP / 4;
     constexpr int STRIDE4 = lds_stride_floats(KP) / 4;
     constexpr int NSUB = pick_nsub(KP);
@@ -165,17 +186,20 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
     const int64_t row = rb * TILE + rl;
     const int rec_lane = (h * Geo::RW + g) * 4 + ql;   // this lane's slot inside a 64-slot iteration
     const int rot = lds_rot<G>(lane);
+    const int toff_lds = TOFF + ((lane >> 2) % TREP) * 4 + q;    // this lane's tail float inside an LDS row
 
     int choff[T4];                              // float4 offset of the chunk visited at step t
     #pragma unroll
     for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
 
     f4 fu[T4], acc[T4];
+    float fut = 0.f, acct = 0.f;                // tail element of this lane
     #pragma unroll
     for (int t = 0; t < T4; ++t) { acc[t] = f4{0.f, 0.f, 0.f, 0.f}; fu[t] = f4{0.f, 0.f, 0.f, 0.f}; }
     if (row < cm.n) {
         #pragma unroll
         for (int t = 0; t < T4; ++t) fu[t] = reinterpret_cast<const f4 *>(FU)[row * KP4 + choff[t]];
+        if (TAIL) fut = FU[row * KP + TOFF + q];
     }
 
     for (int64_t cb = 0; cb < cm.ncb; ++cb) {
@@ -201,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                 if (niter > 0) { rawq[d] = recp[(int64_t)id * 64]; if (HASW) wq[d] = w_nz[rbase + (int64_t)id * 64]; }
             }
             ORIANA_SYNC();                    // everybody is done with the previous image
-            stage_rows<KP4, STRIDE4>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
+            stage_rows<KP4, STRIDE4, TREP>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
             ORIANA_SYNC();
             for (int it = 0; it < niter; ++it) {
                 uint32_t rx = (uint32_t)rawq[0], rm = (uint32_t)(rawq[0] >> 32);
@@ -223,13 +247,15 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                     const f4 *vrow = lds + col * STRIDE4;                                             \
                     f4 v[T4];                                                                         \
                     _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) v[tt] = ORIANA_LDS_ROW(vrow, choff[tt]);        \
+                    float vt = 0.f;                                                                   \
+                    if (TAIL) vt = reinterpret_cast<const float *>(vrow)[toff_lds];                   \
                     f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};                                            \
                     _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
                         d01 = __builtin_elementwise_fma(fu[tt].xy, v[tt].xy, d01);                    \
                         d23 = __builtin_elementwise_fma(fu[tt].zw, v[tt].zw, d23);                    \
                     }                                                                                 \
                     const f2 dd = d01 + d23;                                                          \
-                    const float den = group_sum<G>(dd.x + dd.y);                                      \
+                    const float den = group_sum<G>(TAIL ? fmaf(fut, vt, dd.x + dd.y) : dd.x + dd.y);  \
                     const bool ok = den >= DEN_MIN;          /* false for 0, tiny and NaN */          \
                     const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;             \
                     const float sw = HASW ? s * qb_f32<U>(wcur) : s;                                  \
@@ -238,6 +264,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                         acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);             \
                         acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);             \
                     }                                                                                 \
+                    if (TAIL) acct = fmaf(sw, vt, acct);                                              \
                     const bool slow = valid && !ok;          /* NaN = "evaluate me exactly" */       \
                     bad = bad || slow;                                                                \
                     const float sout = slow ? NAN : s;                                                \
@@ -270,17 +297,20 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
     if (row < cm.n) {
         #pragma unroll
         for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + choff[t]] = acc[t];
+        if (TAIL) R[row * KP + TOFF + q] = acct;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // row SpMM with given s (row-side slots):  R_i = sum_j w s FV_j
 // ------------------------------------------------------------------------------------------
-template <int G, int T4, bool HASW>
+template <int G, int T4, int TAIL, bool HASW>
 __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float *__restrict__ s_rs,
                                                    const float *__restrict__ w_nz, const float *__restrict__ FV,
                                                    float *__restrict__ R) {
-    constexpr int KP = 4 * G * T4;
+    constexpr int KP = 4 * G * T4 + G * TAIL;
+    constexpr int TOFF = 4 * G * T4;
+    constexpr int TREP = (G == 4) ? tail_copies(KP, TAIL) : 1;
     constexpr int KP4 = KP / 4;
     constexpr int STRIDE4 = lds_stride_floats(KP) / 4;
     constexpr int NSUB = pick_nsub(KP);
@@ -298,10 +328,12 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
     const int64_t row = rb * TILE + rl;
     const int rec_lane = (h * Geo::RW + g) * 4 + ql;
     const int rot = lds_rot<G>(lane);
+    const int toff_lds = TOFF + ((lane >> 2) % TREP) * 4 + q;
     int choff[T4];
     #pragma unroll
     for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
     f4 acc[T4];
+    float acct = 0.f;
     #pragma unroll
     for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
             uint32_t rm = 0; float sv = 0.f;
             if (niter > 0) { rm = (uint32_t)(recp[0] >> 32); sv = s_rs[rbase]; if (HASW) sv *= w_nz[rbase]; }
             ORIANA_SYNC();
-            stage_rows<KP4, STRIDE4>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
+            stage_rows<KP4, STRIDE4, TREP>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
             ORIANA_SYNC();
             for (int it = 0; it < niter; ++it) {
                 const uint32_t rmc = rm; const float svc = sv;
@@ -336,6 +368,7 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
                         acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                 \
                         acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                 \
                     }                                                                                 \
+                    if (TAIL) acct = fmaf(s, reinterpret_cast<const float *>(vrow)[toff_lds], acct);  \
                 }
                 ORIANA_SPMM_STEP(0)
                 ORIANA_SPMM_STEP(1)
@@ -348,17 +381,20 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
     if (row < cm.n) {
         #pragma unroll
         for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + choff[t]] = acc[t];
+        if (TAIL) R[row * KP + TOFF + q] = acct;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // column pass:  C_j += sum_i s_ij G_i      (grid.y = row bands, combined with float atomics)
 // ------------------------------------------------------------------------------------------
-template <int G, int T4>
+template <int G, int T4, int TAIL>
 __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float *__restrict__ s_cs,
                                                    const float *__restrict__ Gm, float *__restrict__ C,
                                                    const int32_t *__restrict__ work, int64_t rb_per_band) {
-    constexpr int KP = 4 * G * T4;
+    constexpr int KP = 4 * G * T4 + G * TAIL;
+    constexpr int TOFF = 4 * G * T4;
+    constexpr int TREP = (G == 4) ? tail_copies(KP, TAIL) : 1;
     constexpr int KP4 = KP / 4;
     constexpr int STRIDE4 = lds_stride_floats(KP) / 4;
     constexpr int NSUB = pick_nsub(KP);
@@ -388,10 +424,12 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
     const int64_t col = cb * TILE + cl;
     const int ent_lane = (h * Geo::RW + g) * 4 + ql;
     const int rot = lds_rot<G>(lane);
+    const int toff_lds = TOFF + ((lane >> 2) % TREP) * 4 + q;
     int choff[T4];
     #pragma unroll
     for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
     f4 acc[T4];
+    float acct = 0.f;
     #pragma unroll
     for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
@@ -410,18 +448,20 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
                 if (niter > 0) { svq[d] = s_cs[cbase + (int64_t)id * 64]; rvq[d] = cm.ridx[cbase + (int64_t)id * 64]; }
             }
             ORIANA_SYNC();
-            stage_rows<KP4, STRIDE4>(lds, Gm, rb * TILE + rsub * RT, cm.n, RT, tid);
+            stage_rows<KP4, STRIDE4, TREP>(lds, Gm, rb * TILE + rsub * RT, cm.n, RT, tid);
             ORIANA_SYNC();
             // Software pipeline over the steps: the K-vector of step k+1 is read from LDS while the
             // FMAs of step k run (two register images vA / vB), so each wave always has LDS reads in
             // flight.  The first image of an iteration is loaded during the previous one.
             f4 vA[T4], vB[T4];
+            float vAt = 0.f, vBt = 0.f;
 #define ORIANA_COL_LOAD(V, U, SRC_R)                                                                  \
             {                                                                                         \
                 int r = (int)qb_u32<U>(SRC_R);                                                        \
                 if (NSUB > 1) r &= (RT - 1);                                                          \
                 const f4 *vrow = lds + r * STRIDE4;                                                   \
                 _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) V[tt] = ORIANA_LDS_ROW(vrow, choff[tt]); \
+                if (TAIL) V##t = reinterpret_cast<const float *>(vrow)[toff_lds];                     \
             }
 #define ORIANA_COL_FMA(V, U, SRC_S, SRC_R)                                                            \
             {                                                                                         \
@@ -432,6 +472,7 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
                     acc[tt].xy = __builtin_elementwise_fma(ss, V[tt].xy, acc[tt].xy);                 \
                     acc[tt].zw = __builtin_elementwise_fma(ss, V[tt].zw, acc[tt].zw);                 \
                 }                                                                                     \
+                if (TAIL) acct = fmaf(s, V##t, acct);                                                 \
             }
             if (niter > 0) ORIANA_COL_LOAD(vA, 0, rvq[0])
             for (int it = 0; it < niter; ++it) {
@@ -464,6 +505,7 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
             if (acc[t].z != 0.f) atomicAdd(d + 2, acc[t].z);
             if (acc[t].w != 0.f) atomicAdd(d + 3, acc[t].w);
         }
+        if (TAIL && acct != 0.f) atomicAdd(dst + TOFF + q, acct);
     }
 }
 
@@ -557,39 +599,44 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
 // ------------------------------------------------------------------------------------------
 // dispatch on K:  Kp = 4 * G * T4
 // ------------------------------------------------------------------------------------------
-struct KCfg { int G, T4; };
+struct KCfg { int G, T4, TAIL; };
+// Kp = 16 t (+4): the smallest padded width that holds K.  The tail (one extra float per lane)
+// keeps K = 20, 50, 100 ... free of padding work.
 static inline bool pick_cfg(int64_t K, KCfg *c) {
     if (K <= 0) return false;
-    if (K <= 16)  { *c = {4, 1}; return true; }
-    if (K <= 32)  { *c = {4, 2}; return true; }
-    if (K <= 48)  { *c = {4, 3}; return true; }
-    if (K <= 64)  { *c = {4, 4}; return true; }
-    if (K <= 80)  { *c = {4, 5}; return true; }
-    if (K <= 96)  { *c = {4, 6}; return true; }
-    if (K <= 112) { *c = {4, 7}; return true; }
-    if (K <= 128) { *c = {8, 4}; return true; }
-    if (K <= 160) { *c = {8, 5}; return true; }
-    if (K <= 192) { *c = {8, 6}; return true; }
-    if (K <= 224) { *c = {8, 7}; return true; }
-    if (K <= 256) { *c = {16, 4}; return true; }
+    for (int t = 1; t <= 7; ++t) {
+        if (K <= 16 * t) { *c = {4, t, 0}; return true; }
+        if (t <= 6 && K <= 16 * t + 4) { *c = {4, t, 1}; return true; }
+    }
+    if (K <= 128) { *c = {8, 4, 0}; return true; }
+    if (K <= 160) { *c = {8, 5, 0}; return true; }
+    if (K <= 192) { *c = {8, 6, 0}; return true; }
+    if (K <= 224) { *c = {8, 7, 0}; return true; }
+    if (K <= 256) { *c = {16, 4, 0}; return true; }
     return false;
 }
 
-#define ORIANA_FOR_CFG(cfg, CALL)                                  \
-    do {                                                           \
-        if (cfg.G == 4 && cfg.T4 == 1) { CALL(4, 1); }             \
-        else if (cfg.G == 4 && cfg.T4 == 2) { CALL(4, 2); }        \
-        else if (cfg.G == 4 && cfg.T4 == 3) { CALL(4, 3); }        \
-        else if (cfg.G == 4 && cfg.T4 == 4) { CALL(4, 4); }        \
-        else if (cfg.G == 4 && cfg.T4 == 5) { CALL(4, 5); }        \
-        else if (cfg.G == 4 && cfg.T4 == 6) { CALL(4, 6); }        \
-        else if (cfg.G == 4 && cfg.T4 == 7) { CALL(4, 7); }        \
-        else if (cfg.G == 8 && cfg.T4 == 4) { CALL(8, 4); }        \
-        else if (cfg.G == 8 && cfg.T4 == 5) { CALL(8, 5); }        \
-        else if (cfg.G == 8 && cfg.T4 == 6) { CALL(8, 6); }        \
-        else if (cfg.G == 8 && cfg.T4 == 7) { CALL(8, 7); }        \
-        else if (cfg.G == 16 && cfg.T4 == 4) { CALL(16, 4); }      \
-        else return ORIANA_EKRANGE;                                \
+#define ORIANA_FOR_CFG(cfg, CALL)                                                       \
+    do {                                                                                \
+        if (cfg.G == 4 && cfg.T4 == 1 && cfg.TAIL == 0) { CALL(4, 1, 0); }              \
+        else if (cfg.G == 4 && cfg.T4 == 1 && cfg.TAIL == 1) { CALL(4, 1, 1); }         \
+        else if (cfg.G == 4 && cfg.T4 == 2 && cfg.TAIL == 0) { CALL(4, 2, 0); }         \
+        else if (cfg.G == 4 && cfg.T4 == 2 && cfg.TAIL == 1) { CALL(4, 2, 1); }         \
+        else if (cfg.G == 4 && cfg.T4 == 3 && cfg.TAIL == 0) { CALL(4, 3, 0); }         \
+        else if (cfg.G == 4 && cfg.T4 == 3 && cfg.TAIL == 1) { CALL(4, 3, 1); }         \
+        else if (cfg.G == 4 && cfg.T4 == 4 && cfg.TAIL == 0) { CALL(4, 4, 0); }         \
+        else if (cfg.G == 4 && cfg.T4 == 4 && cfg.TAIL == 1) { CALL(4, 4, 1); }         \
+        else if (cfg.G == 4 && cfg.T4 == 5 && cfg.TAIL == 0) { CALL(4, 5, 0); }         \
+        else if (cfg.G == 4 && cfg.T4 == 5 && cfg.TAIL == 1) { CALL(4, 5, 1); }         \
+        else if (cfg.G == 4 && cfg.T4 == 6 && cfg.TAIL == 0) { CALL(4, 6, 0); }         \
+        else if (cfg.G == 4 && cfg.T4 == 6 && cfg.TAIL == 1) { CALL(4, 6, 1); }         \
+        else if (cfg.G == 4 && cfg.T4 == 7 && cfg.TAIL == 0) { CALL(4, 7, 0); }         \
+        else if (cfg.G == 8 && cfg.T4 == 4) { CALL(8, 4, 0); }                          \
+        else if (cfg.G == 8 && cfg.T4 == 5) { CALL(8, 5, 0); }                          \
+        else if (cfg.G == 8 && cfg.T4 == 6) { CALL(8, 6, 0); }                          \
+        else if (cfg.G == 8 && cfg.T4 == 7) { CALL(8, 7, 0); }                          \
+        else if (cfg.G == 16 && cfg.T4 == 4) { CALL(16, 4, 0); }                        \
+        else return ORIANA_EKRANGE;                                                     \
     } while (0)
 
 template <typename KernelT>
@@ -602,22 +649,22 @@ static int set_lds(KernelT kern, size_t bytes) {
     return 0;
 }
 
-static inline size_t lds_bytes(int G, int T4) {
-    const int KP = 4 * G * T4;
+static inline size_t lds_bytes(int G, int T4, int TAIL) {
+    const int KP = 4 * G * T4 + G * TAIL;
     return (size_t)(TILE / pick_nsub(KP)) * lds_stride_floats(KP) * sizeof(float);
 }
 
-template <int G, int T4>
+template <int G, int T4, int TAIL>
 static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
                            float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s) {
     const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
-    const size_t lb = lds_bytes(G, T4);
+    const size_t lb = lds_bytes(G, T4, TAIL);
     const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
 #define ORIANA_RP(V)                                                                                  \
-    rc = set_lds(k_row_pass<G, T4, V>, lb);                                                           \
+    rc = set_lds(k_row_pass<G, T4, TAIL, V>, lb);                                                           \
     if (rc) return rc;                                                                                \
-    hipLaunchKernelGGL((k_row_pass<G, T4, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
+    hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
     if (var == 0) { ORIANA_RP(0); }
     else if (var == 1) { ORIANA_RP(1); }
     else if (var == 2) { ORIANA_RP(2); }
@@ -627,33 +674,33 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
     return 0;
 }
 
-template <int G, int T4>
+template <int G, int T4, int TAIL>
 static int launch_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz, const float *FV,
                            float *R, hipStream_t s) {
     const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
-    const size_t lb = lds_bytes(G, T4);
+    const size_t lb = lds_bytes(G, T4, TAIL);
     int rc;
     if (w_nz) {
-        rc = set_lds(k_row_spmm<G, T4, true>, lb); if (rc) return rc;
-        hipLaunchKernelGGL((k_row_spmm<G, T4, true>), grid, block, lb, s, *cm, s_rs, w_nz, FV, R);
+        rc = set_lds(k_row_spmm<G, T4, TAIL, true>, lb); if (rc) return rc;
+        hipLaunchKernelGGL((k_row_spmm<G, T4, TAIL, true>), grid, block, lb, s, *cm, s_rs, w_nz, FV, R);
     } else {
-        rc = set_lds(k_row_spmm<G, T4, false>, lb); if (rc) return rc;
-        hipLaunchKernelGGL((k_row_spmm<G, T4, false>), grid, block, lb, s, *cm, s_rs, w_nz, FV, R);
+        rc = set_lds(k_row_spmm<G, T4, TAIL, false>, lb); if (rc) return rc;
+        hipLaunchKernelGGL((k_row_spmm<G, T4, TAIL, false>), grid, block, lb, s, *cm, s_rs, w_nz, FV, R);
     }
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
-template <int G, int T4>
+template <int G, int T4, int TAIL>
 static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C,
                            const int32_t *work, int64_t nwork, hipStream_t s) {
     constexpr int SPLIT = WaveGeo<G>::SPLIT;
-    const size_t lbw = lds_bytes(G, T4);
+    const size_t lbw = lds_bytes(G, T4, TAIL);
     if (work) {
         if (nwork <= 0) return 0;
-        int rcw = set_lds(k_col_pass<G, T4>, lbw);
+        int rcw = set_lds(k_col_pass<G, T4, TAIL>, lbw);
         if (rcw) return rcw;
-        hipLaunchKernelGGL((k_col_pass<G, T4>), dim3((unsigned)(nwork * SPLIT)), dim3(1024), lbw, s, *cm, s_cs, Gm, C,
+        hipLaunchKernelGGL((k_col_pass<G, T4, TAIL>), dim3((unsigned)(nwork * SPLIT)), dim3(1024), lbw, s, *cm, s_cs, Gm, C,
                            work, (int64_t)0);
         ORIANA_LAUNCH_CHECK();
         return 0;
@@ -667,10 +714,10 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const flo
     const int64_t per = (cm->nrb + nb - 1) / nb;
     nb = (cm->nrb + per - 1) / per;
     const dim3 grid((unsigned)(cm->ncb * SPLIT), (unsigned)nb), block(1024);
-    const size_t lb = lds_bytes(G, T4);
-    int rc = set_lds(k_col_pass<G, T4>, lb);
+    const size_t lb = lds_bytes(G, T4, TAIL);
+    int rc = set_lds(k_col_pass<G, T4, TAIL>, lb);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_col_pass<G, T4>), grid, block, lb, s, *cm, s_cs, Gm, C, (const int32_t *)nullptr, per);
+    hipLaunchKernelGGL((k_col_pass<G, T4, TAIL>), grid, block, lb, s, *cm, s_cs, Gm, C, (const int32_t *)nullptr, per);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
@@ -682,7 +729,7 @@ using namespace oriana;
 extern "C" int64_t oriana_kpad(int64_t K) {
     KCfg c;
     if (!pick_cfg(K, &c)) return 0;
-    return 4 * c.G * c.T4;
+    return 4 * c.G * c.T4 + c.G * c.TAIL;
 }
 
 extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.2"; }
@@ -719,7 +766,7 @@ extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const f
     if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
     if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T) return launch_row_pass<G, T>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s)
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -733,7 +780,7 @@ extern "C" int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const
     if (cm->n == 0) return 0;
     if (!R || (cm->m > 0 && !FV) || (cm->rslots > 0 && !s_rs)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T) return launch_row_spmm<G, T>(cm, s_rs, w_nz, FV, R, s)
+#define CALL(G, T, L) return launch_row_spmm<G, T, L>(cm, s_rs, w_nz, FV, R, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -748,7 +795,7 @@ extern "C" int oriana_col_pass(const oriana_counts *cm, const float *s_cs, const
     if (!Gm || !C || !s_cs) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (nwork < 0 || (work == nullptr && nwork != 0)) return ORIANA_EINVAL;
-#define CALL(G, T) return launch_col_pass<G, T>(cm, s_cs, Gm, C, work, nwork, s)
+#define CALL(G, T, L) return launch_col_pass<G, T, L>(cm, s_cs, Gm, C, work, nwork, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;

@@ -40,7 +40,7 @@ def test_binding_table_matches_header():
 def test_kpad_and_version(lib):
     lib.oriana_kpad.restype = ctypes.c_int64
     lib.oriana_kpad.argtypes = [ctypes.c_int64]
-    assert lib.oriana_kpad(5) == 16 and lib.oriana_kpad(20) == 32 and lib.oriana_kpad(100) == 112
+    assert lib.oriana_kpad(5) == 16 and lib.oriana_kpad(20) == 20 and lib.oriana_kpad(100) == 100 and lib.oriana_kpad(101) == 112
     assert lib.oriana_kpad(256) == 256 and lib.oriana_kpad(0) == 0 and lib.oriana_kpad(257) == 0
     lib.oriana_version.restype = ctypes.c_char_p
     assert b'gfx950' in lib.oriana_version()

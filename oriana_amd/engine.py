@@ -362,9 +362,10 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
          base, nbytes, stream_ptr())
 
 
-def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None):
-    """The four loop nests on the resident tiles, for entries whose dropout posterior is 1 at the
-    non-zero counts (always the case inside the models, zigap.py:135):
+def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None, w_nz=None):
+    """The four loop nests on the resident tiles.  `w_nz` = D_hat at the stored entries (row-side
+    slots, CountTiles.side_nz); None means 1, which is always the case inside the models
+    (zigap.py:135 sets the dropout posterior of every non-zero count to 1 in float32):
       Z_i[i,k]   = sum_j [S_hat[j,k]] r_ijk                    (gap.py:79, sparse_gap.py:95)
       Z_j[j,k]   = sum_i [dq[i,k]] r_ijk                       (gap.py:80; dq = D_hat[:, :K], zigap.py:94)
       Z_log[j,k] = sum_i r_ijk (lu_ik + lv_jk)                 (zigap.py:95) -- skipped when Z_log is None
@@ -376,6 +377,9 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
     sparse = S_hat is not None
     if sparse and ws.s_rs is None:
         ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
+    if w_nz is not None and ws.sw_cs is None:
+        ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
+    sw_cs = ws.sw_cs if w_nz is not None else None
     st = stream_ptr()
     factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
     factor_prep(ws.FV, log_V_hat, mask=S_tilde, row_index=ct.col_perm)
@@ -383,38 +387,60 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
     if Z_log is not None:
         Z_log.zero_()
     with _span(ws, 'row_pass'):
-        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None,
+        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
              ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
     with _span(ws, 'fixup'):
-        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, ptr(ws.s_rs) if sparse else None,
-             ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), None, ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
-             K, (1 if sparse else 0) | (4 if dq is not None else 0), st)
+        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs), ptr(ws.s_rs) if sparse else None,
+             ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
+             K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
     R = ws.R
     if sparse:
         F2 = ws.extra('FVS', m)
         call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
         with _span(ws, 'row_spmm'):
-            call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), None, ptr(F2), ptr(ws.R), K, st)
+            call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), ptr(w_nz), ptr(F2), ptr(ws.R), K, st)
     call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(R), None, ptr(ct.row_perm), n, K, 1, st)
-    G = ws.FU
+    # per-gene sums: weighted by D_hat[i, j] (sw), or -- zigap.py:94 -- by D_hat[i, k] on the plain s
+    G, s_for_j = ws.FU, (sw_cs if sw_cs is not None else ws.s_cs)
     if dq is not None:
-        G = ws.extra('GQ', n)
+        G, s_for_j = ws.extra('GQ', n), ws.s_cs
         call('oriana_scale_factor', ptr(G), ptr(ws.FU), ptr(dq), ptr(ct.row_perm), n, K, 0, st)
     with _span(ws, 'col_pass'):
-        col_pass(ct, ws.s_cs, G, ws.C, K)
+        col_pass(ct, s_for_j, G, ws.C, K)
     call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
     if Z_log is not None:
         _check_f32(Z_log, (m, K))
-        if dq is not None:                      # the log sums use the un-weighted column sums
+        s_log = sw_cs if sw_cs is not None else ws.s_cs
+        if dq is not None:                      # the log sums use the D_hat[i, j]-weighted column sums
             ws.C.zero_()
-            col_pass(ct, ws.s_cs, ws.FU, ws.C, K)
+            col_pass(ct, s_log, ws.FU, ws.C, K)
         G2 = ws.extra('GL', n)
         C2 = ws.extra('C2', m)
         C2.zero_()
         call('oriana_scale_factor', ptr(G2), ptr(ws.FU), ptr(log_U_hat), ptr(ct.row_perm), n, K, 1, st)
         with _span(ws, 'col_pass_log'):
-            col_pass(ct, ws.s_cs, G2, C2, K)
+            col_pass(ct, s_log, G2, C2, K)
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ptr(ct.col_perm), m, K, st)
+
+
+def zq_dense(Z_i, Z_j, Z_log, log_U_hat, log_V_hat, X, S_tilde=None, S_hat=None, D_hat=None, quirk=False):
+    """The reference's loop-nest signatures on dense float32 device tensors (zigap.py:79-95,
+    sparse_gap.py:81-97, sparse_zigap.py:100-116): packs X (and gathers D_hat at the non-zeros)
+    on every call, like the reference re-casts X on every call."""
+    for t in (Z_i, Z_j, log_U_hat, log_V_hat, X) + tuple(a for a in (Z_log, S_tilde, S_hat, D_hat) if a is not None):
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
+            raise TypeError('expected 2-D C-contiguous float32 device tensors')
+    n, K = log_U_hat.shape
+    m = log_V_hat.shape[0]
+    _check_f32(X, (n, m))
+    ct = CountTiles.from_dense(X, X.device, side=D_hat)
+    ws = ZWorkspace(ct, K)
+    dq = None
+    if quirk:
+        if D_hat is None or K > m:
+            raise ValueError('the zigap.py:94 quirk needs D_hat and K <= number of genes')
+        dq = D_hat[:, :K].contiguous()
+    zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=S_tilde, S_hat=S_hat, dq=dq, w_nz=ct.side_nz)
 
 
 def _check_f32(t, shape):

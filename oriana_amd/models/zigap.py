@@ -128,6 +128,14 @@ class ZIGaP(_ZIMixin, FactorModel):
     """ZI-pCMF (reference zigap.py:15-165)."""
     zi = True
 
+    @staticmethod
+    def compute_Z_q_expectations(DZ_hat_i, DZ_hat_j, DZ_exp_logsum_hat, log_U_hat, log_V_hat, D_hat, X,
+                                 reference_quirks=True):
+        """Drop-in for zigap.py:79-95 on dense float32 device tensors (outputs first, zero-filled
+        here, returns None).  reference_quirks keeps the D_hat[i, k] index of zigap.py:94."""
+        engine.zq_dense(DZ_hat_i, DZ_hat_j, DZ_exp_logsum_hat, log_U_hat, log_V_hat, X, D_hat=D_hat,
+                        quirk=reference_quirks)
+
     def _init_extra(self):
         self._init_zi()
 
@@ -165,6 +173,11 @@ class SparseGaP(_SparseMixin, FactorModel):
     """Sparse pCMF (reference sparse_gap.py:15-172; the NameError of sparse_gap.py:127 -- a bare
     `S_hat` -- is read as the evident self.S_hat, SURVEY.md 8(a) policy)."""
     sparse = True
+
+    @staticmethod
+    def compute_Z_q_expectations(SZ_hat_i, Z_hat_j, Z_exp_logsum_hat, log_U_hat, log_V_hat, S_tilde, S_hat, X):
+        """Drop-in for sparse_gap.py:81-97 on dense float32 device tensors."""
+        engine.zq_dense(SZ_hat_i, Z_hat_j, Z_exp_logsum_hat, log_U_hat, log_V_hat, X, S_tilde=S_tilde, S_hat=S_hat)
 
     def _init_extra(self):
         self._init_sparse()
@@ -206,6 +219,12 @@ class SparseZIGaP(_ZIMixin, _SparseMixin, FactorModel):
     """Sparse ZI-pCMF (reference sparse_zigap.py:15-204)."""
     zi = True
     sparse = True
+
+    @staticmethod
+    def compute_Z_q_expectations(DSZ_hat, DZ_hat, DZ_exp_logsum_hat, log_U_hat, log_V_hat, S_tilde, S_hat, D_hat, X):
+        """Drop-in for sparse_zigap.py:100-116 on dense float32 device tensors."""
+        engine.zq_dense(DSZ_hat, DZ_hat, DZ_exp_logsum_hat, log_U_hat, log_V_hat, X, S_tilde=S_tilde, S_hat=S_hat,
+                        D_hat=D_hat)
 
     def _init_extra(self):
         self._init_zi()

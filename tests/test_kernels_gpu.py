@@ -249,3 +249,32 @@ def test_zq_sparse_random(eng, K):
     for got, ref in zip((Zi, Zj, Zl), r):
         assert err_colrel(got.cpu().numpy(), ref) < RTOL
     assert not Zj.cpu().numpy()[5].any()
+
+
+@pytest.mark.parametrize('name', ['ZIGaP', 'SparseGaP', 'SparseZIGaP'])
+def test_variant_dropins_general_D(eng, name):
+    """Model.compute_Z_q_expectations(...) with the reference's argument order on dense device
+    tensors, with a GENERAL D_hat (not 1 at the non-zeros): exercises the weighted kernels."""
+    import oriana_amd.models as M
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(11)
+    n, m, K = 300, 280, 20
+    X = _rand_counts(rng, n, m, 0.2).astype(np.float32)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    lu[3] = -1e15; lv[7] -= 70.0                       # slow-path entries too
+    D = rng.random((n, m)).astype(np.float32)
+    ps = rng.random((m, K)); St = (ps > 0.4).astype(np.float32); Sh = ps.astype(np.float32)
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    o = [torch.full((n, K), 3.0, device='cuda'), torch.full((m, K), 3.0, device='cuda'), torch.full((m, K), 3.0, device='cuda')]
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    if name == 'ZIGaP':
+        assert M.ZIGaP.compute_Z_q_expectations(o[0], o[1], o[2], c(lu), c(lv), c(D), c(X)) is None
+        co.zq_zigap(r[0], r[1], r[2], lu, lv, D, X, quirk=True)
+    elif name == 'SparseGaP':
+        M.SparseGaP.compute_Z_q_expectations(o[0], o[1], o[2], c(lu), c(lv), c(St), c(Sh), c(X))
+        co.zq_sparse_gap(r[0], r[1], r[2], lu, lv, St, Sh, X)
+    else:
+        M.SparseZIGaP.compute_Z_q_expectations(o[0], o[1], o[2], c(lu), c(lv), c(St), c(Sh), c(D), c(X))
+        co.zq_sparse_zigap(r[0], r[1], r[2], lu, lv, St, Sh, D, X)
+    for got, ref in zip(o, r):
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL

@@ -113,3 +113,52 @@ def test_oracle_agreement_medium():
         O.load_state(M.state())
         M.step(); O.step()
         assert_state_close(M.state(), O.state(), what='sweep %d' % it)
+
+
+@pytest.mark.parametrize('name', ['GaP', 'ZIGaP', 'SparseGaP', 'SparseZIGaP'])
+def test_oracle_agreement_multi_tile(name):
+    """Sizes the golden files do not cover (several row / column tiles, K = 20 with a tail chunk):
+    each HIP sweep against the oracle sweep started from the same state."""
+    import oriana_amd.models as M
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(5)
+    n, m, K = 600, 530, 20
+    X = (rng.poisson(4.0, size=(n, m)) * (rng.random((n, m)) < rng.beta(1, 4, size=m))).astype(np.int64)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    G = getattr(M, name)(X, k=K, init=(a1, b1))
+    O = co.MODELS[name](X, K, a1, b1)
+    assert_state_close(G.state(), O.state(), what='init')
+    for it in range(2):
+        O.load_state(G.state())
+        if O.zi:
+            O.D_hat = O.p_d.astype(np.float32)
+        G.step(); O.step()
+        assert_state_close(G.state(), O.state(), what='%s sweep %d' % (name, it),
+                           ps_tol=sparsity_tolerance(O) if O.sparse else None)
+
+
+def test_config2_full_size_properties():
+    """BASELINE.json configs[1] (10k x 2k, K = 20) at full size: conservation properties of a
+    sweep (responsibilities sum to the counts) and agreement of the responsibility sums with the
+    C oracle on the whole matrix."""
+    from oracle import cavi_oracle as co
+    from oriana_amd import engine
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K = 10000, 2000, 20
+    gen = SyntheticCounts(n, m, K, seed=2234, device='cuda', zero_inflation_level=0.1)
+    X = gen.chunk(0, n)
+    ct = engine.CountTiles.from_dense(X, 'cuda')
+    ws = engine.ZWorkspace(ct, K)
+    a1, b1 = gen.initial_shapes()
+    lu = torch.digamma(a1.float().double()).float().contiguous(); lv = torch.digamma(b1.float().double()).float().contiguous()
+    Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda')
+    engine.zq_gap(ws, Zi, Zj, lu, lv)
+    Xh = X.cpu().numpy()
+    np.testing.assert_allclose(Zi.sum(1).cpu().numpy(), Xh.sum(1), rtol=2e-5)
+    np.testing.assert_allclose(Zj.sum(1).cpu().numpy(), Xh.sum(0), rtol=2e-5, atol=1e-2)
+    rZi = np.empty((n, K), np.float32); rZj = np.empty((m, K), np.float32)
+    co.zq_gap(rZi, rZj, lu.cpu().numpy(), lv.cpu().numpy(), np.ascontiguousarray(Xh))
+    from helpers import err_colrel
+    assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5
+    # the oracle accumulates 10,000 float32 terms left to right; its own error is ~1e-5 there
+    assert err_colrel(Zj.cpu().numpy(), rZj) < 5e-5

@@ -115,6 +115,7 @@ class FactorModel:
         self.V = _Buffer(lambda: self._effective_V())
         self.UV = _Buffer(lambda: self._U_hat @ self._effective_V().t())          # lazy Einsum('nk,mk->nm')
         self.n_sweeps = 0
+        self._graph = None
         self.initialize_parameters()
 
     # ---- initial shapes -------------------------------------------------------------------------
@@ -151,9 +152,32 @@ class FactorModel:
 
     def step(self):
         """One CAVI sweep (base.py:54-56)."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._sweep()
+        self.n_sweeps += 1
+
+    def _sweep(self):
         self.update_variational_parameters()   # E-step
         self.update_prior_hyper_parameters()   # M-step
-        self.n_sweeps += 1
+
+    def capture_graph(self):
+        """Capture one sweep into a hipGraph and replay it from step() on (single process only:
+        the launches of a sweep have no host-side decision, so small problems stop being
+        launch-bound).  The state tensors are updated in place, exactly as without the graph."""
+        if self.world > 1:
+            raise RuntimeError('graph capture is for single-process models (collectives are not captured)')
+        if self._graph is not None:
+            return self
+        self._sweep()                          # warm-up: allocations, lazy scratch buffers
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._sweep()
+        self.n_sweeps += 1                     # the warm-up sweep
+        self._graph = g
+        return self
 
     def fit(self, n_iter=50):
         """The loop user scripts write around step() (reference main.py:37-51)."""

@@ -162,3 +162,16 @@ def test_config2_full_size_properties():
     assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5
     # the oracle accumulates 10,000 float32 terms left to right; its own error is ~1e-5 there
     assert err_colrel(Zj.cpu().numpy(), rZj) < 5e-5
+
+
+def test_graph_replay_matches_eager():
+    """A sweep captured in a hipGraph and replayed gives the eager sweeps' state."""
+    g = load_golden(golden_files('gap_c1_rand.npz')[0])
+    A = _make(g); B = _make(g)
+    A.fit(4)
+    B.capture_graph()           # runs sweep 1 eagerly (warm-up); the captured sweep has not run yet
+    B.fit(3)
+    assert B.n_sweeps == 4
+    sa, sb = A.state(), B.state()
+    for k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'beta2'):
+        np.testing.assert_allclose(sb[k], sa[k], rtol=1e-4)

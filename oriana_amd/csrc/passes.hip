@@ -107,37 +107,62 @@ __device__ __forceinline__ int lds_rot(int lane) {
 template <int U> __device__ __forceinline__ uint32_t qb_u32(uint32_t v) { return quad_bcast_u32<U>(v); }
 template <int U> __device__ __forceinline__ float qb_f32(float v) { return quad_bcast_f32<U>(v); }
 
-// stage `rows` factor rows starting at global row j0 (bounded by jmax) into an LDS image
+// Staging of `rows` factor rows (global rows j0 .., bounded by jmax) into an LDS image, split in
+// two halves so that the global loads are issued BEFORE the barrier that waits for the previous
+// image's readers (their latency overlaps the wait) and only the LDS stores come after it.
 // With a tail (TAILREP > 1) the last float4 of a row is replicated TAILREP times behind the row:
 // the quads of a wave read their tail float from different copies, i.e. from different LDS banks
 // (rows are 512 bytes apart, so without this every quad of a ds_read_b32 would hit the same 4 banks).
-template <int KP4, int STRIDE4, int TAILREP = 1>
-__device__ __forceinline__ void stage_rows(f4 *img, const float *__restrict__ F, int64_t j0, int64_t jmax,
-                                           int rows, int tid) {
-#ifdef ORIANA_ABLATE_NOSTAGE
-    if (j0 > 0) return;
-#endif
-    for (int idx = tid; idx < rows * KP4; idx += 1024) {
-        const int jr = idx / KP4, c4 = idx - jr * KP4;
-        const int64_t j = j0 + jr;
-        // rows past the end are zero-filled: padding slots point at image row 0 and must read finite values
-        img[jr * STRIDE4 + c4] = (j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + c4] : f4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (TAILREP > 1) {
-        // the extra copies of the tail float4: one store per thread and copy, all lanes busy
-        for (int idx = tid; idx < rows * (TAILREP - 1); idx += 1024) {
-            const int jr = idx / (TAILREP - 1), rep = idx - jr * (TAILREP - 1) + 1;
+template <int KP4, int TAILREP, int ROWS>
+struct Stage {
+    static constexpr int NST = (ROWS * KP4 + 1023) / 1024;                       // float4 per thread
+    static constexpr int NTR = (TAILREP > 1) ? (ROWS * (TAILREP - 1) + 1023) / 1024 : 1;
+    f4 v[NST];
+    f4 t[NTR];
+
+    __device__ __forceinline__ void load(const float *__restrict__ F, int64_t j0, int64_t jmax, int tid) {
+        // launder the thread index: the per-element index arithmetic must be redone per tile, not
+        // hoisted out of the tile loop into a dozen long-lived address registers
+        asm volatile("" : "+v"(tid));
+        #pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = tid + u * 1024;
+            const int jr = idx / KP4, c4 = idx - jr * KP4;
             const int64_t j = j0 + jr;
-            img[jr * STRIDE4 + (KP4 - 1) + rep] =
-                (j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + (KP4 - 1)] : f4{0.f, 0.f, 0.f, 0.f};
+            // rows past the end are zero-filled: padding slots point at image row 0 and must read finite values
+            v[u] = (idx < ROWS * KP4 && j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + c4] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (TAILREP > 1) {
+            #pragma unroll
+            for (int u = 0; u < NTR; ++u) {
+                const int idx = tid + u * 1024;
+                const int64_t j = j0 + idx / (TAILREP - 1);
+                t[u] = (idx < ROWS * (TAILREP - 1) && j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + (KP4 - 1)]
+                                                               : f4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
-}
 
-// Geometry of a wave inside the 1024-thread workgroup.
-//   RW  = rows (columns) owned by one wave = 64 / G
-//   a 16-row slice is shared by WPS = 16 / RW waves; wave `w` handles sub-slice h = w % WPS
-//   the workgroup covers 16 * RW rows = SPLIT-th part of the 256-row block
+    template <int STRIDE4>
+    __device__ __forceinline__ void store(f4 *img, int tid) const {
+        asm volatile("" : "+v"(tid));
+        #pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = tid + u * 1024;
+            const int jr = idx / KP4, c4 = idx - jr * KP4;
+            if (idx < ROWS * KP4) img[jr * STRIDE4 + c4] = v[u];
+        }
+        if (TAILREP > 1) {
+            #pragma unroll
+            for (int u = 0; u < NTR; ++u) {
+                const int idx = tid + u * 1024;
+                const int jr = idx / (TAILREP - 1), rep = idx - jr * (TAILREP - 1) + 1;
+                if (idx < ROWS * (TAILREP - 1)) img[jr * STRIDE4 + (KP4 - 1) + rep] = t[u];
+            }
+        }
+    }
+};
+
 // copies of the tail that fit behind a row of KP floats inside its 256-byte aligned stride
 constexpr int tail_copies(int KP, int TAIL) {
     if (!TAIL) return 1;
@@ -224,8 +249,10 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                 rawq[d] = 0ull; wq[d] = 1.0f;
                 if (niter > 0) { rawq[d] = recp[(int64_t)id * 64]; if (HASW) wq[d] = w_nz[rbase + (int64_t)id * 64]; }
             }
+            Stage<KP4, TREP, CT> stg;
+            stg.load(FV, cb * TILE + csub * CT, cm.m, tid);
             ORIANA_SYNC();                    // everybody is done with the previous image
-            stage_rows<KP4, STRIDE4, TREP>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
+            stg.template store<STRIDE4>(lds, tid);
             ORIANA_SYNC();
             for (int it = 0; it < niter; ++it) {
                 uint32_t rx = (uint32_t)rawq[0], rm = (uint32_t)(rawq[0] >> 32);
@@ -346,8 +373,10 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
         for (int csub = 0; csub < NSUB; ++csub) {
             uint32_t rm = 0; float sv = 0.f;
             if (niter > 0) { rm = (uint32_t)(recp[0] >> 32); sv = s_rs[rbase]; if (HASW) sv *= w_nz[rbase]; }
+            Stage<KP4, TREP, CT> stg;
+            stg.load(FV, cb * TILE + csub * CT, cm.m, tid);
             ORIANA_SYNC();
-            stage_rows<KP4, STRIDE4, TREP>(lds, FV, cb * TILE + csub * CT, cm.m, CT, tid);
+            stg.template store<STRIDE4>(lds, tid);
             ORIANA_SYNC();
             for (int it = 0; it < niter; ++it) {
                 const uint32_t rmc = rm; const float svc = sv;
@@ -447,34 +476,14 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
                 svq[d] = 0.f; rvq[d] = 0;
                 if (niter > 0) { svq[d] = s_cs[cbase + (int64_t)id * 64]; rvq[d] = cm.ridx[cbase + (int64_t)id * 64]; }
             }
+            Stage<KP4, TREP, RT> stg;
+            stg.load(Gm, rb * TILE + rsub * RT, cm.n, tid);
             ORIANA_SYNC();
-            stage_rows<KP4, STRIDE4, TREP>(lds, Gm, rb * TILE + rsub * RT, cm.n, RT, tid);
+            stg.template store<STRIDE4>(lds, tid);
             ORIANA_SYNC();
-            // Software pipeline over the steps: the K-vector of step k+1 is read from LDS while the
-            // FMAs of step k run (two register images vA / vB), so each wave always has LDS reads in
-            // flight.  The first image of an iteration is loaded during the previous one.
-            f4 vA[T4], vB[T4];
-            float vAt = 0.f, vBt = 0.f;
-#define ORIANA_COL_LOAD(V, U, SRC_R)                                                                  \
-            {                                                                                         \
-                int r = (int)qb_u32<U>(SRC_R);                                                        \
-                if (NSUB > 1) r &= (RT - 1);                                                          \
-                const f4 *vrow = lds + r * STRIDE4;                                                   \
-                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) V[tt] = ORIANA_LDS_ROW(vrow, choff[tt]); \
-                if (TAIL) V##t = reinterpret_cast<const float *>(vrow)[toff_lds];                     \
-            }
-#define ORIANA_COL_FMA(V, U, SRC_S, SRC_R)                                                            \
-            {                                                                                         \
-                float s = qb_f32<U>(SRC_S);                                                           \
-                if (NSUB > 1) { if ((int)qb_u32<U>(SRC_R) / RT != rsub) s = 0.f; }                     \
-                const f2 ss = {s, s};                                                                 \
-                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
-                    acc[tt].xy = __builtin_elementwise_fma(ss, V[tt].xy, acc[tt].xy);                 \
-                    acc[tt].zw = __builtin_elementwise_fma(ss, V[tt].zw, acc[tt].zw);                 \
-                }                                                                                     \
-                if (TAIL) acct = fmaf(s, V##t, acct);                                                 \
-            }
-            if (niter > 0) ORIANA_COL_LOAD(vA, 0, rvq[0])
+            // (An explicit two-image software pipeline of the LDS reads was measured and bought
+            // nothing: the pass is bound by LDS throughput, not latency; the compiler already keeps
+            // 4-6 reads in flight.)
             for (int it = 0; it < niter; ++it) {
                 const float svc = svq[0]; const uint32_t rvc = rvq[0];
                 #pragma unroll
@@ -482,17 +491,26 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
                 const int nx = (it + CPD < niter) ? it + CPD : niter - 1;
                 svq[CPD - 1] = s_cs[cbase + (int64_t)nx * 64];
                 rvq[CPD - 1] = cm.ridx[cbase + (int64_t)nx * 64];
-                ORIANA_COL_LOAD(vB, 1, rvc)
-                ORIANA_COL_FMA(vA, 0, svc, rvc)
-                ORIANA_COL_LOAD(vA, 2, rvc)
-                ORIANA_COL_FMA(vB, 1, svc, rvc)
-                ORIANA_COL_LOAD(vB, 3, rvc)
-                ORIANA_COL_FMA(vA, 2, svc, rvc)
-                ORIANA_COL_LOAD(vA, 0, rvq[0])          // first step of the next iteration (padding-safe: row 0)
-                ORIANA_COL_FMA(vB, 3, svc, rvc)
+#define ORIANA_COL_STEP(U)                                                                            \
+                {                                                                                     \
+                    float s = qb_f32<U>(svc);                                                         \
+                    int r = (int)qb_u32<U>(rvc);                                                      \
+                    if (NSUB > 1) { if (r / RT != rsub) s = 0.f; r &= (RT - 1); }                      \
+                    const f4 *vrow = lds + r * STRIDE4;                                               \
+                    const f2 ss = {s, s};                                                             \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        const f4 v = ORIANA_LDS_ROW(vrow, choff[tt]);                                 \
+                        acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                 \
+                        acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                 \
+                    }                                                                                 \
+                    if (TAIL) acct = fmaf(s, reinterpret_cast<const float *>(vrow)[toff_lds], acct);  \
+                }
+                ORIANA_COL_STEP(0)
+                ORIANA_COL_STEP(1)
+                ORIANA_COL_STEP(2)
+                ORIANA_COL_STEP(3)
+#undef ORIANA_COL_STEP
             }
-#undef ORIANA_COL_LOAD
-#undef ORIANA_COL_FMA
         }
     }
     if (col < cm.m) {

@@ -216,7 +216,14 @@ int oriana_colsum_f64(double *out, const double *A, const float *mul, int64_t r,
  *   oriana_colsum_wide_f64: out[j] += sum_i A[i, j]  (pi_d = mean(p_d, axis=0), zigap.py:158).
  */
 int oriana_dropout_update(double *p_d, float *D_hat, const double *Lambda, const double *pi_d,
+                          /* optional: bit mask of X != 0 (oriana_nzmask_f32 layout) -> the override
+                           * p_d[X != 0] = 1 - 1e-10 is applied in the same pass */
+                          const uint32_t *nzmask,
+                          /* optional: colsum[j] += sum_i p_d[i, j] (zero it first) */
+                          double *colsum,
                           int64_t rows, int64_t m, void *stream);
+/* mask[i][w] bit b = (D[i, 32 w + b] != 0); ceil(m / 32) words per row. */
+int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, int64_t m, void *stream);
 int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
 int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);
 /* dq[i, k] = D[i, k], k < K: the columns the reference's zigap.py:94 reads (D_hat[i, k]). */

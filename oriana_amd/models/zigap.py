@@ -35,6 +35,10 @@ class _ZIMixin:
         call('oriana_dropout_fix_nz', self.counts.c_struct, ptr(p_d), ptr(self._D_hat), 1.0, stream_ptr())
         self.p_d = Parameter(p_d)
         self._pd_sum = torch.zeros(m, dtype=torch.float64, device=dev)
+        # bit mask of X != 0 (constant): lets the D update apply p_d[X != 0] = 1 - 1e-10 in its own pass
+        self._nzmask = torch.zeros(max(n, 1) * ((m + 31) // 32), dtype=torch.int32, device=dev)
+        call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._D_hat), n, m, stream_ptr())
+        self._pd_sum_fresh = False
 
     @property
     def D_hat(self):
@@ -42,11 +46,16 @@ class _ZIMixin:
 
     def _refresh_D_hat(self):
         self._D_hat.copy_(self.p_d.tensor)              # Bernoulli.mean: float32 cast (bernoulli.py:45)
+        self._pd_sum_fresh = False
 
     def _mstep_pi_d(self):
-        """pi_d = mean(p_d, axis=0) (zigap.py:158), summed over the row shards."""
-        self._pd_sum.zero_()
-        call('oriana_colsum_wide_f64', ptr(self._pd_sum), ptr(self.p_d.tensor), self.n, self.m, stream_ptr())
+        """pi_d = mean(p_d, axis=0) (zigap.py:158), summed over the row shards.  The column sums
+        come for free from the D update of the same sweep; they are recomputed only when p_d was
+        set from outside (initialisation, load_state)."""
+        if not self._pd_sum_fresh:
+            self._pd_sum.zero_()
+            call('oriana_colsum_wide_f64', ptr(self._pd_sum), ptr(self.p_d.tensor), self.n, self.m, stream_ptr())
+        self._pd_sum_fresh = False
         odist.all_reduce_sum(self._pd_sum, self.pg)
         torch.div(self._pd_sum, float(self.n_total), out=self.pi_d.tensor)
 
@@ -73,9 +82,10 @@ class _ZIMixin:
         """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat."""
         st = stream_ptr()
         torch.matmul(self._U_hat, V_for_d.t(), out=self.p_d.tensor)        # Lambda, written into the p_d buffer
+        self._pd_sum.zero_()
         call('oriana_dropout_update', ptr(self.p_d.tensor), ptr(self._D_hat), ptr(self.p_d.tensor),
-             ptr(self.pi_d.tensor), self.n, self.m, st)
-        call('oriana_dropout_fix_nz', self.counts.c_struct, ptr(self.p_d.tensor), ptr(self._D_hat), 1.0 - 1e-10, st)
+             ptr(self.pi_d.tensor), ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, st)
+        self._pd_sum_fresh = True
 
 
 class _SparseMixin:

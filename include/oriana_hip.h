@@ -224,6 +224,17 @@ int oriana_dropout_update(double *p_d, float *D_hat, const double *Lambda, const
                           int64_t rows, int64_t m, void *stream);
 /* mask[i][w] bit b = (D[i, 32 w + b] != 0); ceil(m / 32) words per row. */
 int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, int64_t m, void *stream);
+/* The same update with Lambda = U_hat V_hat^T formed on the matrix cores inside the kernel (f64 MFMA),
+ * so that Lambda never goes through HBM: U (n, K), V (m, K) f64 row-major, K <= 256. */
+int oriana_dropout_update_fused(double *p_d, float *D_hat, const double *U, const double *V, const double *pi_d,
+                                const uint32_t *nzmask, double *colsum, int64_t n, int64_t m, int64_t K,
+                                void *stream);
+/* Rate terms of the ZI Gamma updates on the matrix cores, D_hat (n, m) f32 read in place and promoted
+ * to f64 as np.dot does:  trans = 0: out[n, K] += D_hat W[m, K]   (zigap.py:116, np.dot(D_hat, V_hat))
+ *                         trans = 1: out[m, K] += D_hat^T W[n, K] (zigap.py:124, np.dot(D_hat.T, U_hat))
+ * `out` must be initialised (zeros for a plain product).  K <= 256. */
+int oriana_dense_times_factor(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
+                              int trans, void *stream);
 int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
 int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);
 /* dq[i, k] = D[i, k], k < K: the columns the reference's zigap.py:94 reads (D_hat[i, k]). */

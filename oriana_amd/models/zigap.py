@@ -6,8 +6,9 @@ The responsibility sums run on the resident non-zero tiles (engine.zq); the drop
 exactly 1 (in float32) at every non-zero count -- zigap.py:135 sets p_d[X != 0] = 1 - 1e-10 and
 Bernoulli.mean casts to float32 (bernoulli.py:45) -- so the loop nests never need D_hat[i, j] at
 the non-zeros.  The three dense contractions of the ZI models (D_hat V_hat, D_hat^T U_hat,
-U_hat V_hat^T: zigap.py:116, 124, 132) are plain float64 GEMMs and go through rocBLAS
-(torch.matmul); everything around them is in the element-wise kernels of csrc/dense.hip.
+U_hat V_hat^T: zigap.py:116, 124, 132) run in float64 on the matrix cores (csrc/dense_mfma.hip):
+the first two read the float32 D_hat in place, the third is fused with the sigmoid / override /
+column-sum epilogue so that Lambda is never materialised.
 """
 import numpy as np
 import torch
@@ -19,8 +20,6 @@ from ..parameters import Parameter
 from .base import FactorModel
 
 __all__ = ['ZIGaP', 'SparseGaP', 'SparseZIGaP']
-
-_ROW_CHUNK_BYTES = 2 << 30
 
 
 class _ZIMixin:
@@ -59,32 +58,27 @@ class _ZIMixin:
         odist.all_reduce_sum(self._pd_sum, self.pg)
         torch.div(self._pd_sum, float(self.n_total), out=self.pi_d.tensor)
 
-    def _rows_per_chunk(self):
-        return max(256, int(_ROW_CHUNK_BYTES // max(1, self.m * 8)))
-
     def _D_times(self, V):
-        """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K)."""
-        out = torch.empty(self.n, self.k, dtype=torch.float64, device=self.device)
-        step = self._rows_per_chunk()
-        for r0 in range(0, self.n, step):
-            torch.matmul(self._D_hat[r0:r0 + step].double(), V, out=out[r0:r0 + step])
+        """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K), f64 MFMA."""
+        out = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
+        call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(V.contiguous()), self.n, self.m, self.k, 0,
+             stream_ptr())
         return out
 
     def _Dt_times(self, U):
-        """np.dot(D_hat.T, U) (zigap.py:124), summed over the row shards.  (m, K)."""
+        """np.dot(D_hat.T, U) (zigap.py:124), summed over the row shards.  (m, K), f64 MFMA."""
         out = torch.zeros(self.m, self.k, dtype=torch.float64, device=self.device)
-        step = self._rows_per_chunk()
-        for r0 in range(0, self.n, step):
-            out.addmm_(self._D_hat[r0:r0 + step].double().t(), U[r0:r0 + step])
+        call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m, self.k, 1,
+             stream_ptr())
         return odist.all_reduce_sum(out, self.pg)
 
     def _update_D(self, V_for_d):
-        """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat."""
-        st = stream_ptr()
-        torch.matmul(self._U_hat, V_for_d.t(), out=self.p_d.tensor)        # Lambda, written into the p_d buffer
+        """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat; one fused
+        kernel that also leaves the column sums of p_d for the pi_d M-step."""
         self._pd_sum.zero_()
-        call('oriana_dropout_update', ptr(self.p_d.tensor), ptr(self._D_hat), ptr(self.p_d.tensor),
-             ptr(self.pi_d.tensor), ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, st)
+        call('oriana_dropout_update_fused', ptr(self.p_d.tensor), ptr(self._D_hat), ptr(self._U_hat),
+             ptr(V_for_d.contiguous()), ptr(self.pi_d.tensor), ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m,
+             self.k, stream_ptr())
         self._pd_sum_fresh = True
 
 

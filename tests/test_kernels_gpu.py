@@ -278,3 +278,71 @@ def test_variant_dropins_general_D(eng, name):
         co.zq_sparse_zigap(r[0], r[1], r[2], lu, lv, St, Sh, D, X)
     for got, ref in zip(o, r):
         assert err_colrel(got.cpu().numpy(), ref) < RTOL
+
+
+# ---- dense f64 products of the ZI models on the matrix cores (csrc/dense_mfma.hip) ------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,m,K', [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 1024, 100),
+                                   (260, 300, 130), (70, 90, 256), (5000, 3001, 50)])
+@pytest.mark.parametrize('trans', [0, 1])
+def test_dense_times_factor(n, m, K, trans):
+    import torch
+    from oriana_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator(device='cpu').manual_seed(n * 7 + m * 3 + K + trans)
+    D = torch.rand(n, m, generator=g, dtype=torch.float32)
+    D[D < 0.3] = 0.0
+    W = torch.rand(n if trans else m, K, generator=g, dtype=torch.float64) * 3.0
+    Dd, Wd = D.cuda(), W.cuda()
+    out = torch.zeros(m if trans else n, K, dtype=torch.float64, device='cuda')
+    call('oriana_dense_times_factor', ptr(out), ptr(Dd), ptr(Wd), n, m, K, trans, stream_ptr())
+    torch.cuda.synchronize()
+    ref = (D.double().t() @ W) if trans else (D.double() @ W)
+    # f64 products, summation order differs from BLAS: 1e-12 relative
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-12, atol=1e-12)
+    # accumulating call: out += product
+    call('oriana_dense_times_factor', ptr(out), ptr(Dd), ptr(Wd), n, m, K, trans, stream_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), 2.0 * ref.numpy(), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,m,K', [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 1024, 100),
+                                   (70, 90, 256), (2000, 1500, 0)])
+def test_dropout_update_fused_matches_unfused(n, m, K):
+    """The fused MFMA kernel against the two-step path (f64 GEMM + oriana_dropout_update)."""
+    import torch
+    from oriana_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator(device='cpu').manual_seed(n + 3 * m + 11 * K)
+    U = (torch.rand(n, K, generator=g, dtype=torch.float64) * 2.0).cuda()
+    V = (torch.rand(m, K, generator=g, dtype=torch.float64) * 2.0).cuda()
+    pi = torch.rand(m, generator=g, dtype=torch.float64)
+    if m > 4:
+        pi[1] = 0.0
+        pi[3] = 1.0
+    pi = pi.cuda()
+    X = (torch.rand(n, m, generator=g) < 0.2).float().cuda()
+    mw = (m + 31) // 32
+    mask = torch.zeros(n * mw, dtype=torch.int32, device='cuda')
+    call('oriana_nzmask_f32', ptr(mask), ptr(X), n, m, stream_ptr())
+    p1 = torch.empty(n, m, dtype=torch.float64, device='cuda')
+    D1 = torch.empty(n, m, dtype=torch.float32, device='cuda')
+    cs1 = torch.zeros(m, dtype=torch.float64, device='cuda')
+    call('oriana_dropout_update_fused', ptr(p1), ptr(D1), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs1), n, m, K,
+         stream_ptr())
+    lam = U @ V.t() if K else torch.zeros(n, m, dtype=torch.float64, device='cuda')
+    p2 = torch.empty_like(p1)
+    D2 = torch.empty_like(D1)
+    cs2 = torch.zeros_like(cs1)
+    call('oriana_dropout_update', ptr(p2), ptr(D2), ptr(lam.contiguous()), ptr(pi), ptr(mask), ptr(cs2), n, m,
+         stream_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(D1.cpu().numpy(), D2.cpu().numpy(), rtol=2e-7)
+    np.testing.assert_allclose(cs1.cpu().numpy(), cs2.cpu().numpy(), rtol=1e-11)
+    # the overrides are exact
+    p1h, Xh = p1.cpu().numpy(), X.cpu().numpy()
+    assert np.all(p1h[Xh != 0] == 1.0 - 1e-10)
+    if m > 4:
+        assert np.all(p1h[:, 1][Xh[:, 1] == 0] == 1e-10)
+        assert np.all(p1h[:, 3] == 1.0 - 1e-10)

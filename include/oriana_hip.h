@@ -222,7 +222,7 @@ int oriana_dropout_update(double *p_d, float *D_hat, const double *Lambda, const
                           /* optional: colsum[j] += sum_i p_d[i, j] (zero it first) */
                           double *colsum,
                           int64_t rows, int64_t m, void *stream);
-/* mask[i][w] bit b = (D[i, 32 w + b] != 0); ceil(m / 32) words per row. */
+/* mask[(i / 32) * m + j] bit (i % 32) = (D[i, j] != 0); ceil(rows / 32) * m words. */
 int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, int64_t m, void *stream);
 /* The same update with Lambda = U_hat V_hat^T formed on the matrix cores inside the kernel (f64 MFMA),
  * so that Lambda never goes through HBM: U (n, K), V (m, K) f64 row-major, K <= 256. */

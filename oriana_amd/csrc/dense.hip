@@ -10,11 +10,11 @@ namespace oriana {
 
 // p_d[i,j] = sigmoid(logit(pi_d[j]) - Lambda[i,j]);  column overrides for pi_d <= 0 / >= 1
 // (zigap.py:131-134);  D_hat = float32(p_d) (bernoulli.py:45).  Lambda may alias p_d (in place).
-// nzmask (optional): bit j of row i set iff X[i, j] != 0, rows padded to mw 32-bit words -- then the
-// override p_d[X != 0] = 1 - 1e-10 (zigap.py:135) is applied here.  colsum (optional): += sum_i p_d[i, j].
+// nzmask (optional): word [(i / 32) * m + j] bit (i % 32) set iff X[i, j] != 0 (oriana_nzmask_f32) -- then
+// the override p_d[X != 0] = 1 - 1e-10 (zigap.py:135) is applied here.  colsum (optional): += sum_i p_d[i, j].
 __global__ __launch_bounds__(256) void k_dropout_update(double *__restrict__ p_d, float *__restrict__ D_hat,
                                                         const double *Lambda, const double *__restrict__ pi_d,
-                                                        const uint32_t *__restrict__ nzmask, int64_t mw,
+                                                        const uint32_t *__restrict__ nzmask,
                                                         double *__restrict__ colsum, int64_t rows, int64_t m) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
@@ -22,13 +22,19 @@ __global__ __launch_bounds__(256) void k_dropout_update(double *__restrict__ p_d
     const double lg = logit_f64(pi);
     const int64_t r0 = (int64_t)blockIdx.y * 64;
     const int64_t r1 = (r0 + 64 < rows) ? r0 + 64 : rows;
+    uint32_t w0 = 0, w1 = 0;
+    if (nzmask) {
+        w0 = nzmask[(r0 >> 5) * m + j];
+        if (r0 + 32 < rows) w1 = nzmask[((r0 >> 5) + 1) * m + j];
+    }
     double cs = 0.0;
     for (int64_t i = r0; i < r1; ++i) {
         const int64_t idx = i * m + j;
         double p = sigmoid_f64(lg - Lambda[idx]);
         if (pi <= 0.0) p = 1e-10;
         if (pi >= 1.0) p = 1.0 - 1e-10;
-        if (nzmask && ((nzmask[i * mw + (j >> 5)] >> (j & 31)) & 1u)) p = 1.0 - 1e-10;
+        const int b = (int)(i - r0);
+        if (((b < 32 ? w0 >> b : w1 >> (b - 32)) & 1u)) p = 1.0 - 1e-10;
         p_d[idx] = p;
         D_hat[idx] = (float)p;
         cs += p;
@@ -36,18 +42,18 @@ __global__ __launch_bounds__(256) void k_dropout_update(double *__restrict__ p_d
     if (colsum) atomicAdd(&colsum[j], cs);
 }
 
-// bit mask of the non-zero entries of a dense (rows, m) f32 matrix, mw words per row
+// bit mask of the non-zero entries of a dense (rows, m) f32 matrix: one word per (32 rows, column)
 __global__ __launch_bounds__(256) void k_nzmask(uint32_t *__restrict__ mask, const float *__restrict__ D, int64_t rows,
-                                                int64_t m, int64_t mw) {
-    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;      // word index inside the row
-    const int64_t i = blockIdx.y;
-    if (w >= mw) return;
+                                                int64_t m) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t w = blockIdx.y;                                   // block of 32 rows
+    if (j >= m) return;
     uint32_t bits = 0;
     for (int b = 0; b < 32; ++b) {
-        const int64_t j = w * 32 + b;
-        if (j < m && D[i * m + j] != 0.f) bits |= (1u << b);
+        const int64_t i = w * 32 + b;
+        if (i < rows && D[i * m + j] != 0.f) bits |= (1u << b);
     }
-    mask[i * mw + w] = bits;
+    mask[w * m + j] = bits;
 }
 
 // p_d[X != 0] = 1 - 1e-10 (zigap.py:135): one thread per row-side slot of the tiled layout.
@@ -181,12 +187,11 @@ extern "C" int oriana_dropout_update(double *p_d, float *D_hat, const double *La
     if (rows < 0 || m < 0) return ORIANA_EINVAL;
     if (rows == 0 || m == 0) return 0;
     if (!p_d || !D_hat || !Lambda || !pi_d) return ORIANA_EINVAL;
-    const int64_t mw = (m + 31) / 32;
     for (int64_t y0 = 0; y0 * 64 < rows; y0 += 65535) {
         const int64_t ny = ((rows + 63) / 64 - y0 < 65535) ? (rows + 63) / 64 - y0 : 65535;
         hipLaunchKernelGGL(k_dropout_update, dim3((unsigned)((m + 255) / 256), (unsigned)ny), dim3(256), 0,
                            (hipStream_t)stream, p_d + y0 * 64 * m, D_hat + y0 * 64 * m, Lambda + y0 * 64 * m, pi_d,
-                           nzmask ? nzmask + y0 * 64 * mw : nullptr, mw, colsum, rows - y0 * 64, m);
+                           nzmask ? nzmask + y0 * 2 * m : nullptr, colsum, rows - y0 * 64, m);
     }
     ORIANA_LAUNCH_CHECK();
     return 0;
@@ -196,11 +201,11 @@ extern "C" int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, i
     if (rows < 0 || m < 0) return ORIANA_EINVAL;
     if (rows == 0 || m == 0) return 0;
     if (!mask || !D) return ORIANA_EINVAL;
-    const int64_t mw = (m + 31) / 32;
-    for (int64_t y0 = 0; y0 < rows; y0 += 65535) {
-        const int64_t ny = (rows - y0 < 65535) ? rows - y0 : 65535;
-        hipLaunchKernelGGL(k_nzmask, dim3((unsigned)((mw + 255) / 256), (unsigned)ny), dim3(256), 0, (hipStream_t)stream,
-                           mask + y0 * mw, D + y0 * m, ny, m, mw);
+    const int64_t nw = (rows + 31) / 32;
+    for (int64_t y0 = 0; y0 < nw; y0 += 65535) {
+        const int64_t ny = (nw - y0 < 65535) ? nw - y0 : 65535;
+        hipLaunchKernelGGL(k_nzmask, dim3((unsigned)((m + 255) / 256), (unsigned)ny), dim3(256), 0, (hipStream_t)stream,
+                           mask + y0 * m, D + y0 * 32 * m, rows - y0 * 32, m);
     }
     ORIANA_LAUNCH_CHECK();
     return 0;

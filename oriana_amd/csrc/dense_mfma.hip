@@ -11,6 +11,7 @@
 //   A[row = lane & 15][k = lane >> 4],  B[k = lane >> 4][col = lane & 15],
 //   D reg r: [row = (lane >> 4) + 4 r][col = lane & 15].
 #include "common.h"
+#include <stdlib.h>
 
 namespace oriana {
 
@@ -152,11 +153,13 @@ __global__ __launch_bounds__(256) void k_dense_times_factor(double *__restrict__
 }
 
 // Fused D_q update.  Work-group = one 256 x 256 block of (cells, genes); the 64-row U_hat sub-block
-// lives in LDS (A operand), V_hat fragments come from L2 (B operand), the reduction runs over K.
-__global__ __launch_bounds__(256) void k_dropout_fused(double *__restrict__ p_d, float *__restrict__ D_hat,
+// lives in LDS (A operand), V_hat fragments come from L2 four reduction steps ahead of their use
+// (B operand), the reduction runs over K.  nzmask: oriana_nzmask_f32 layout, two words per lane
+// cover the 64 rows of a sub-block.
+__global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p_d, float *__restrict__ D_hat,
                                                        const double *__restrict__ U, const double *__restrict__ V,
                                                        const double *__restrict__ pi_d,
-                                                       const uint32_t *__restrict__ nzmask, int64_t mw,
+                                                       const uint32_t *__restrict__ nzmask,
                                                        double *__restrict__ colsum, int64_t n, int64_t m, int K,
                                                        int KS, int us) {
     extern __shared__ double Us[];                      // [64][us]
@@ -167,67 +170,120 @@ __global__ __launch_bounds__(256) void k_dropout_fused(double *__restrict__ p_d,
     const int g = lane >> 4;
     const int64_t i_blk = (int64_t)blockIdx.y * 256;
     const int64_t j_blk = (int64_t)blockIdx.x * 256;
+    const int kcols = KS * 4;
 
     double cs[4] = {0.0, 0.0, 0.0, 0.0};
-    double lg[4], piv[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int64_t j = j_blk + (wave * 4 + ct) * 16 + lr;
-        piv[ct] = (j < m) ? pi_d[j] : 0.5;
-        lg[ct] = logit_f64(piv[ct]);
-    }
 
+    // operands of one (row sub-block, column tile) step that come from global memory; those of the
+    // next step are requested before the current step's stores are issued, so that waiting for them
+    // does not also wait for the stores (one in-order counter covers both)
+    struct TileIn { double bq[4]; double pi; uint32_t w0, w1; };
+    auto fetch = [&](TileIn &t, int64_t i0, int ct) {
+        const int64_t j = j_blk + (wave * 4 + ct) * 16 + lr;
+        const bool ok = (j < m) && (i0 < n);
+        const double *vrow = V + (ok ? j : 0) * K;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * u + g;
+            t.bq[u] = (ok && k < K) ? vrow[k] : 0.0;
+        }
+        t.pi = ok ? pi_d[j] : 0.5;
+        t.w0 = 0;
+        t.w1 = 0;
+#ifndef ORIANA_ABL_NOMASK
+        if (nzmask && ok) {
+            t.w0 = nzmask[(i0 >> 5) * m + j];
+            if (i0 + 32 < n) t.w1 = nzmask[((i0 >> 5) + 1) * m + j];
+        }
+#endif
+    };
+
+    TileIn cur;
+    fetch(cur, i_blk, 0);
     for (int rsub = 0; rsub < 4; ++rsub) {
         const int64_t i0 = i_blk + rsub * 64;
         if (i0 >= n) break;                             // uniform over the work-group
         __syncthreads();
-        for (int idx = tid; idx < 64 * KS * 4; idx += 256) {
-            const int rr = idx / (KS * 4);
-            const int kk = idx % (KS * 4);
+        for (int rr = tid >> 4; rr < 64; rr += 16) {    // 16 threads per row of the sub-block
             const int64_t i = i0 + rr;
-            Us[rr * us + kk] = (i < n && kk < K) ? U[i * K + kk] : 0.0;
+            for (int kk = tid & 15; kk < kcols; kk += 16)
+                Us[rr * us + kk] = (i < n && kk < K) ? U[i * K + kk] : 0.0;
         }
         __syncthreads();
 #pragma unroll 1
         for (int ct = 0; ct < 4; ++ct) {
-            const int64_t j0 = j_blk + (wave * 4 + ct) * 16;
-            if (j0 >= m) break;
-            const int64_t j = j0 + lr;
+            const int64_t j = j_blk + (wave * 4 + ct) * 16 + lr;
             const bool jok = j < m;
             const double *vrow = V + (jok ? j : 0) * K;
             d4 acc[4];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[rt] = (d4){0.0, 0.0, 0.0, 0.0};
-            double b = (jok && g < K) ? vrow[g] : 0.0;
-#pragma unroll 2
-            for (int ks = 0; ks < KS; ++ks) {
-                const int kn = 4 * (ks + 1) + g;
-                const double bn = (jok && kn < K) ? vrow[kn] : 0.0;     // next step's fragment, in flight
+#pragma unroll 1
+            for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+                double bn[4];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-                    const double a = Us[(rt * 16 + lr) * us + 4 * ks + g];
-                    acc[rt] = mfma_f64(a, b, acc[rt]);
+                for (int u = 0; u < 4; ++u) {                       // next group's fragments, in flight
+                    const int k = 4 * (ks0 + 4 + u) + g;
+                    bn[u] = (jok && k < K) ? vrow[k] : 0.0;
                 }
-                b = bn;
-            }
-            if (jok) {
-                const double pi = piv[ct];
-                double csum = 0.0;
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
+                for (int u = 0; u < 4; ++u) {
+                    if (ks0 + u < KS) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t i = i0 + rt * 16 + g + 4 * r;
-                        if (i < n) {
-                            double p = sigmoid_f64(lg[ct] - acc[rt][r]);
-                            if (pi <= 0.0) p = 1e-10;
-                            if (pi >= 1.0) p = 1.0 - 1e-10;
-                            if (nzmask && ((nzmask[i * mw + (j >> 5)] >> (j & 31)) & 1u)) p = 1.0 - 1e-10;
-                            p_d[i * m + j] = p;
-                            D_hat[i * m + j] = (float)p;
-                            csum += p;
+                        for (int rt = 0; rt < 4; ++rt) {
+                            const double a = Us[(rt * 16 + lr) * us + 4 * (ks0 + u) + g];
+#ifdef ORIANA_ABL_NOMFMA
+                            acc[rt][0] += a * cur.bq[u];
+#else
+                            acc[rt] = mfma_f64(a, cur.bq[u], acc[rt]);
+#endif
                         }
                     }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cur.bq[u] = bn[u];
+            }
+            const double pi = cur.pi;
+            const uint32_t w0 = cur.w0, w1 = cur.w1;
+            fetch(cur, (ct == 3) ? i0 + 64 : i0, (ct + 1) & 3);
+            if (jok) {
+                const double lg = logit_f64(pi);
+                double csum = 0.0;
+                // element (rt, r) sits in row i0 + g + 4 (4 rt + r): one running offset, 4 m per step (kept
+                // opaque so that the 16 addresses are not all formed -- and spilled -- ahead of the loop)
+                int64_t off = (i0 + g) * m + j;
+                const int64_t step = 4 * m;
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    __builtin_amdgcn_sched_barrier(0);      // one row tile at a time: keeps the f64 exp chains' registers low
+                    const uint32_t w = (rt < 2) ? w0 : w1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int bit = (rt & 1) * 16 + g + 4 * r;
+                        const int64_t i = i0 + rt * 16 + g + 4 * r;
+                        asm volatile("" : "+v"(off));
+                        if (i < n) {
+#ifdef ORIANA_ABL_NOSIG
+                            double p = lg - acc[rt][r];
+#else
+                            double p = sigmoid_f64(lg - acc[rt][r]);
+#endif
+                            if (pi <= 0.0) p = 1e-10;
+                            if (pi >= 1.0) p = 1.0 - 1e-10;
+                            if ((w >> bit) & 1u) p = 1.0 - 1e-10;
+#ifdef ORIANA_ABL_NOSTORE
+                            if (p == 12345.678) {
+#else
+                            {
+#endif
+                                p_d[off] = p;
+                                D_hat[off] = (float)p;
+                            }
+                            csum += p;
+                        }
+                        off += step;
+                    }
+                }
                 cs[ct] += csum;
             }
         }
@@ -247,11 +303,14 @@ __global__ __launch_bounds__(256) void k_dropout_fused(double *__restrict__ p_d,
 template <int NT, int T, int TRANS>
 static int launch_dtf(double *out, const float *D, const double *W, int64_t P, int64_t Q, int K, hipStream_t st) {
     const int64_t pb = (P + 4 * T * 16 - 1) / (4 * T * 16);
-    // enough work-groups for ~8 per CU; q slices are multiples of the chunk
-    int64_t splits = (2048 + pb - 1) / pb;
+    // >= 16 slices of the reduction range (measured best for both orientations at 100k x 20k), more
+    // when there are few p blocks; q slices are multiples of the chunk
+    int64_t splits = (1024 + pb - 1) / pb;
+    if (splits < 16) splits = 16;
     const int64_t max_splits = (Q + 4 * QC - 1) / (4 * QC);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    if (const char *e = getenv("ORIANA_DTF_SPLITS")) splits = atoi(e);
     if (splits > 65535) splits = 65535;
     int64_t qps = (Q + splits - 1) / splits;
     qps = (qps + QC - 1) / QC * QC;
@@ -313,7 +372,7 @@ extern "C" int oriana_dropout_update_fused(double *p_d, float *D_hat, const doub
         for (int64_t r0 = 0; r0 < n; r0 += slab) {
             const int64_t rows = (n - r0 < slab) ? n - r0 : slab;
             int rc = oriana_dropout_update_fused(p_d + r0 * m, D_hat + r0 * m, U + r0 * K, V, pi_d,
-                                                 nzmask ? nzmask + r0 * ((m + 31) / 32) : nullptr, colsum, rows, m, K,
+                                                 nzmask ? nzmask + (r0 / 32) * m : nullptr, colsum, rows, m, K,
                                                  stream);
             if (rc) return rc;
         }
@@ -323,7 +382,7 @@ extern "C" int oriana_dropout_update_fused(double *p_d, float *D_hat, const doub
         ORIANA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dropout_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds));
     hipLaunchKernelGGL(k_dropout_fused, dim3((unsigned)ncb, (unsigned)nrb), dim3(256), lds, (hipStream_t)stream, p_d,
-                       D_hat, U, V, pi_d, nzmask, (m + 31) / 32, colsum, n, m, (int)K, KS, us);
+                       D_hat, U, V, pi_d, nzmask, colsum, n, m, (int)K, KS, us);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -35,7 +35,7 @@ class _ZIMixin:
         self.p_d = Parameter(p_d)
         self._pd_sum = torch.zeros(m, dtype=torch.float64, device=dev)
         # bit mask of X != 0 (constant): lets the D update apply p_d[X != 0] = 1 - 1e-10 in its own pass
-        self._nzmask = torch.zeros(max(n, 1) * ((m + 31) // 32), dtype=torch.int32, device=dev)
+        self._nzmask = torch.zeros(((n + 31) // 32) * max(m, 1), dtype=torch.int32, device=dev)
         call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._D_hat), n, m, stream_ptr())
         self._pd_sum_fresh = False
 

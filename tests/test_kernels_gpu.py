@@ -322,8 +322,7 @@ def test_dropout_update_fused_matches_unfused(n, m, K):
         pi[3] = 1.0
     pi = pi.cuda()
     X = (torch.rand(n, m, generator=g) < 0.2).float().cuda()
-    mw = (m + 31) // 32
-    mask = torch.zeros(n * mw, dtype=torch.int32, device='cuda')
+    mask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device='cuda')
     call('oriana_nzmask_f32', ptr(mask), ptr(X), n, m, stream_ptr())
     p1 = torch.empty(n, m, dtype=torch.float64, device='cuda')
     D1 = torch.empty(n, m, dtype=torch.float32, device='cuda')

@@ -33,6 +33,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
+LDS_PEAK_GBS = 256 * 128 * 2.4   # 256 CUs x 128 B/clk x 2.4 GHz = 78.6 TB/s
+
+
+def recorded_traffic(workload, world):
+    """HBM bytes per launch of the pass from the committed PMC run (profiles/): the counters need
+    their own rocprofv3 passes, so the bench line quotes the recorded measurement for the
+    configuration it was taken on and null elsewhere."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_%s.json' % workload)
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)['traffic_bytes_per_pass']['total'])
+    except Exception:
+        return None
 
 WORKLOADS = {
     # name: (n_total, m, K, zero_inflation_level)
@@ -130,6 +146,10 @@ def main():
     Kp = engine.kpad(K)
     design_bytes = counts.nnz * 17.0 + counts.nrb * counts.ncb * (2 * 257 * 4.0 + 16) + 4.0 * Kp * (3 * n + 3 * m)
     achieved = alg_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+    # the pass is bound by the CU-side rates, not by HBM: useful flops
+    # (6 per non-zero and factor) and useful LDS bytes (two K-vector reads per non-zero)
+    useful_tflops = 6.0 * counts.nnz * K / (pass_ms * 1e-3) / 1e12 if pass_ms > 0 else 0.0
+    useful_lds_gbs = 8.0 * counts.nnz * K / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
     check = float(model.alpha1.tensor.sum().item() + model.beta1.tensor.sum().item())
 
     cpu = None
@@ -148,11 +168,16 @@ def main():
                        'n_cells': n_total, 'n_genes': m, 'K': K, 'nnz': nnz_total, 'rows_per_rank': n,
                        'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': recorded_traffic(args.workload, world),
                          'kernel': 'responsibility pass = k_row_pass + k_fixup + k_col_pass (rank 0 shard)',
                          'algorithmic_bytes': alg_bytes, 'design_bytes': design_bytes,
                          'row_pass_ms': row_ms, 'col_pass_ms': col_ms, 'fixup_ms': fix_ms,
-                         'achieved_design_bytes': design_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0},
+                         'achieved_design_bytes': design_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
+                         'valu': {'achieved': useful_tflops, 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': useful_tflops / VALU_PEAK_TFLOPS},
+                         'lds': {'achieved': useful_lds_gbs, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': useful_lds_gbs / LDS_PEAK_GBS},
+                         'slot_efficiency': counts.slot_efficiency()},
             'cpu_baseline': cpu,
             'check': check,
         }

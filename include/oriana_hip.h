@@ -169,14 +169,36 @@ int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag,
                  int64_t K, int variant, void *stream);
 
 /* ---- stateless drop-ins with the reference's exact signatures (outputs first) ------------------
- * X dense (n, m) f32.  `ws` is caller-provided scratch of at least oriana_zq_workspace_bytes()
- * bytes (256-byte aligned); these entry points pack X on every call, as the reference re-casts X
- * on every call (gap.py:94).  The model classes use the resident oriana_counts instead.
+ * One entry per loop nest, arguments in the reference's order, all matrices dense C-contiguous f32
+ * on the device: X, D_hat (n, m); log_U_hat and the row-side output (n, K); log_V_hat, S_tilde, S_hat
+ * and the gene-side outputs (m, K).  The callee zero-fills the outputs (gap.py:69-70).  `ws` is
+ * caller-provided scratch of at least oriana_zq_workspace_bytes() bytes (256-byte aligned); these
+ * entry points pack X on every call, as the reference re-casts X on every call (gap.py:94), and
+ * synchronise the stream once (the slot totals size the record arrays).  The model classes use the
+ * resident oriana_counts instead.
+ *   oriana_zq_gap_f32          GaP.compute_Z_q_expectations          oriana/models/gap.py:67-80
+ *   oriana_zq_zigap_f32        ZIGaP.compute_Z_q_expectations        oriana/models/zigap.py:79-95
+ *                              reference_quirks != 0 keeps the D_hat[i, k] index of zigap.py:94
+ *                              (needs K <= m); 0 weights the per-gene sums with D_hat[i, j]
+ *   oriana_zq_sparse_gap_f32   SparseGaP.compute_Z_q_expectations    oriana/models/sparse_gap.py:81-97
+ *   oriana_zq_sparse_zigap_f32 SparseZIGaP.compute_Z_q_expectations  oriana/models/sparse_zigap.py:100-116
  */
 int64_t oriana_zq_workspace_bytes(int64_t n, int64_t m, int64_t K, int64_t nnz_bound);
 int oriana_zq_gap_f32(float *Z_hat_i, float *Z_hat_j,
                       const float *log_U_hat, const float *log_V_hat, const float *X,
                       int64_t n, int64_t m, int64_t K, void *ws, int64_t ws_bytes, void *stream);
+int oriana_zq_zigap_f32(float *DZ_hat_i, float *DZ_hat_j, float *DZ_exp_logsum_hat,
+                        const float *log_U_hat, const float *log_V_hat, const float *D_hat, const float *X,
+                        int64_t n, int64_t m, int64_t K, int reference_quirks,
+                        void *ws, int64_t ws_bytes, void *stream);
+int oriana_zq_sparse_gap_f32(float *SZ_hat_i, float *Z_hat_j, float *Z_exp_logsum_hat,
+                             const float *log_U_hat, const float *log_V_hat,
+                             const float *S_tilde, const float *S_hat, const float *X,
+                             int64_t n, int64_t m, int64_t K, void *ws, int64_t ws_bytes, void *stream);
+int oriana_zq_sparse_zigap_f32(float *DSZ_hat, float *DZ_hat, float *DZ_exp_logsum_hat,
+                               const float *log_U_hat, const float *log_V_hat,
+                               const float *S_tilde, const float *S_hat, const float *D_hat, const float *X,
+                               int64_t n, int64_t m, int64_t K, void *ws, int64_t ws_bytes, void *stream);
 
 /* ---- Gamma / Bernoulli updates and the M-step --------------------------------------------------
  * oriana_gamma_update: one side (U or V) of update_variational_parameters

@@ -40,6 +40,9 @@ _SIGS = {
                              _I, c_int, _P]),
     'oriana_zq_workspace_bytes': (c_int64, [_I, _I, _I, _I]),
     'oriana_zq_gap_f32': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    'oriana_zq_zigap_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, c_int, _P, _I, _P]),
+    'oriana_zq_sparse_gap_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    'oriana_zq_sparse_zigap_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     'oriana_gamma_update': (c_int, [_P] * 13 + [_I, _I, _P]),
     'oriana_mstep_gamma': (c_int, [_P, _P, _P, _P, c_double, _I, _P]),
     'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),

@@ -353,11 +353,7 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
     n, K = log_U_hat.shape
     m = log_V_hat.shape[0]
     _check_f32(Z_hat_i, (n, K)); _check_f32(Z_hat_j, (m, K)); _check_f32(log_V_hat, (m, K)); _check_f32(X, (n, m))
-    kpad(K)
-    nnz = int(torch.count_nonzero(X).item()) if X.numel() else 0
-    nbytes = int(_lib.load().oriana_zq_workspace_bytes(n, m, K, nnz + 64))
-    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=X.device)
-    base = (ws.data_ptr() + 255) // 256 * 256
+    ws, base, nbytes = _stateless_ws(n, m, K, X)
     call('oriana_zq_gap_f32', ptr(Z_hat_i), ptr(Z_hat_j), ptr(log_U_hat), ptr(log_V_hat), ptr(X), n, m, K,
          base, nbytes, stream_ptr())
 
@@ -423,24 +419,52 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ptr(ct.col_perm), m, K, st)
 
 
+def _stateless_ws(n, m, K, X):
+    kpad(K)
+    nnz = int(torch.count_nonzero(X).item()) if X.numel() else 0
+    nbytes = int(_lib.load().oriana_zq_workspace_bytes(n, m, K, nnz + 64))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=X.device)
+    return ws, (ws.data_ptr() + 255) // 256 * 256, nbytes
+
+
 def zq_dense(Z_i, Z_j, Z_log, log_U_hat, log_V_hat, X, S_tilde=None, S_hat=None, D_hat=None, quirk=False):
     """The reference's loop-nest signatures on dense float32 device tensors (zigap.py:79-95,
-    sparse_gap.py:81-97, sparse_zigap.py:100-116): packs X (and gathers D_hat at the non-zeros)
-    on every call, like the reference re-casts X on every call."""
+    sparse_gap.py:81-97, sparse_zigap.py:100-116) through the stateless C-ABI entries
+    oriana_zq_zigap_f32 / oriana_zq_sparse_gap_f32 / oriana_zq_sparse_zigap_f32: X is packed (and
+    D_hat gathered at the non-zeros) on every call, like the reference re-casts X on every call."""
     for t in (Z_i, Z_j, log_U_hat, log_V_hat, X) + tuple(a for a in (Z_log, S_tilde, S_hat, D_hat) if a is not None):
         if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
             raise TypeError('expected 2-D C-contiguous float32 device tensors')
     n, K = log_U_hat.shape
     m = log_V_hat.shape[0]
-    _check_f32(X, (n, m))
-    ct = CountTiles.from_dense(X, X.device, side=D_hat)
-    ws = ZWorkspace(ct, K)
-    dq = None
-    if quirk:
-        if D_hat is None or K > m:
-            raise ValueError('the zigap.py:94 quirk needs D_hat and K <= number of genes')
-        dq = D_hat[:, :K].contiguous()
-    zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=S_tilde, S_hat=S_hat, dq=dq, w_nz=ct.side_nz)
+    _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_V_hat, (m, K)); _check_f32(X, (n, m))
+    if Z_log is not None:
+        _check_f32(Z_log, (m, K))
+    for t in (S_tilde, S_hat):
+        if t is not None:
+            _check_f32(t, (m, K))
+    if D_hat is not None:
+        _check_f32(D_hat, (n, m))
+    if quirk and (D_hat is None or K > m):
+        raise ValueError('the zigap.py:94 quirk needs D_hat and K <= number of genes')
+    ws, base, nbytes = _stateless_ws(n, m, K, X)
+    st = stream_ptr()
+    if S_hat is None and D_hat is None:
+        if Z_log is not None:
+            raise ValueError('the pCMF loop nest (gap.py:67-80) has no log-sum output')
+        call('oriana_zq_gap_f32', ptr(Z_i), ptr(Z_j), ptr(log_U_hat), ptr(log_V_hat), ptr(X), n, m, K, base, nbytes, st)
+    elif S_hat is None:
+        call('oriana_zq_zigap_f32', ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(log_U_hat), ptr(log_V_hat), ptr(D_hat), ptr(X),
+             n, m, K, 1 if quirk else 0, base, nbytes, st)
+    elif D_hat is None:
+        call('oriana_zq_sparse_gap_f32', ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde),
+             ptr(S_hat), ptr(X), n, m, K, base, nbytes, st)
+    else:
+        if quirk:
+            raise ValueError('sparse_zigap.py:114-116 has no D_hat[i, k] quirk')
+        call('oriana_zq_sparse_zigap_f32', ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde),
+             ptr(S_hat), ptr(D_hat), ptr(X), n, m, K, base, nbytes, st)
+    del ws
 
 
 def _check_f32(t, shape):

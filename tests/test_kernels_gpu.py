@@ -280,6 +280,34 @@ def test_variant_dropins_general_D(eng, name):
         assert err_colrel(got.cpu().numpy(), ref) < RTOL
 
 
+def test_zigap_dropin_corrected_index_and_edges(eng):
+    """oriana_zq_zigap_f32 with reference_quirks = 0 (per-gene sums weighted by D_hat[i, j]) against
+    the oracle's corrected form; all-zero X and empty shapes return zero-filled outputs."""
+    import oriana_amd.models as M
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(5)
+    n, m, K = 270, 131, 7
+    X = _rand_counts(rng, n, m, 0.3).astype(np.float32)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    D = rng.random((n, m)).astype(np.float32)
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    o = [torch.full((n, K), 3.0, device='cuda'), torch.full((m, K), 3.0, device='cuda'), torch.full((m, K), 3.0, device='cuda')]
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    M.ZIGaP.compute_Z_q_expectations(o[0], o[1], o[2], c(lu), c(lv), c(D), c(X), reference_quirks=False)
+    co.zq_zigap(r[0], r[1], r[2], lu, lv, D, X, quirk=False)
+    for got, ref in zip(o, r):
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL
+    # all-zero counts: outputs are zero-filled by the callee
+    M.ZIGaP.compute_Z_q_expectations(o[0], o[1], o[2], c(lu), c(lv), c(D), c(np.zeros_like(X)))
+    assert all(not t.cpu().numpy().any() for t in o)
+    # the quirk needs K <= m (zigap.py:94 would raise IndexError)
+    with pytest.raises(Exception):
+        M.ZIGaP.compute_Z_q_expectations(torch.zeros(4, 9, device='cuda'), torch.zeros(3, 9, device='cuda'),
+                                         torch.zeros(3, 9, device='cuda'), torch.zeros(4, 9, device='cuda'),
+                                         torch.zeros(3, 9, device='cuda'), torch.ones(4, 3, device='cuda'),
+                                         torch.ones(4, 3, device='cuda'))
+
+
 # ---- dense f64 products of the ZI models on the matrix cores (csrc/dense_mfma.hip) ------------------
 
 @pytest.mark.gpu

@@ -90,7 +90,7 @@ template <int G>
 __device__ __forceinline__ int lds_rot(int lane) {
     // ds_read_b128 is serviced in fixed 16-lane sets; quads that are serviced together must start
     // at different 64-byte quarters of the 256-byte bank row.  Measured on MI355X with
-    // scratch/ub/lds_pat.hip (random 512-byte rows, 7 chunks): no rotation 16.5, (Q&7)>>1 6.6,
+    // tools/ubench/lds_pat.hip (random 512-byte rows, 7 chunks): no rotation 16.5, (Q&7)>>1 6.6,
     // this one 6.1, broadcast floor 5.4 cycles per wave-instruction.
 #if defined(ORIANA_ABLATE_ROT0)
     return 0;

@@ -164,6 +164,101 @@ def test_config2_full_size_properties():
     assert err_colrel(Zj.cpu().numpy(), rZj) < 5e-5
 
 
+def _chunk_sums(gen, n, m):
+    """chunk function that also accumulates the exact row / column sums of X (first visit only)."""
+    rows = torch.zeros(n, dtype=torch.float64, device='cuda')
+    cols = torch.zeros(m, dtype=torch.float64, device='cuda')
+    seen = set()
+
+    def chunk(r0, r1):
+        X = gen.chunk(r0, r1)
+        if r0 not in seen:
+            seen.add(r0)
+            rows[r0:r1] = X.sum(1, dtype=torch.float64)
+            cols.add_(X.sum(0, dtype=torch.float64))
+        return X
+    return chunk, rows, cols
+
+
+def test_config4_full_size_properties():
+    """BASELINE.json configs[3] -- the metric's configuration, 1,000,000 x 30,000, K = 100, 3.0e9
+    non-zeros, 4.1e9 slots per side (beyond signed 32-bit indices) -- at full size through the
+    conservation property of the loop nest: for every cell sum_k Z_i[i, k] = sum_j X[i, j], for every
+    gene sum_k Z_j[j, k] = sum_i X[i, j] (gap.py:72-80: the responsibilities of an entry sum to its
+    count), plus one full sweep of the model staying finite and conserving the same sums."""
+    from oriana_amd import engine
+    from oriana_amd.models import GaP
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K = 1000000, 30000, 100
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip('needs ~100 GB of free HBM')
+    gen = SyntheticCounts(n, m, K, seed=5234, device='cuda', zero_inflation_level=0.1)
+    chunk, rows, cols = _chunk_sums(gen, n, m)
+    ct = engine.CountTiles.from_chunks(n, m, chunk, 8192, 'cuda')
+    assert ct.rslots > 2 ** 31 and ct.cslots > 2 ** 31        # slot indices beyond int32, byte offsets beyond 2^34
+    a1, b1 = gen.initial_shapes()
+    model = GaP(ct, k=K, use_factors=False, init=(a1, b1), device='cuda')
+    lu, lv = model._log_U_hat.clone(), model._log_V_hat.clone()
+    Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda')
+    engine.zq_gap(model._ws, Zi, Zj, lu, lv)
+    zi = Zi.sum(1, dtype=torch.float64); zj = Zj.sum(1, dtype=torch.float64)
+    assert torch.isfinite(Zi).all() and torch.isfinite(Zj).all()
+    assert float(((zi - rows).abs() / rows.clamp_min(1.0)).max()) < 2e-5
+    assert float(((zj - cols).abs() / cols.clamp_min(1.0)).max()) < 2e-5
+    # the grand total agrees to float64 summation accuracy of float32 terms
+    assert abs(float(zi.sum()) / float(rows.sum()) - 1.0) < 1e-6
+    assert abs(float(zj.sum()) / float(cols.sum()) - 1.0) < 1e-6
+    # one sweep: a1 - alpha1 = Z_i (gap.py:97) keeps the row sums, all parameters stay finite and clamped
+    alpha1 = model.alpha1.tensor.clone(); beta1 = model.beta1.tensor.clone()
+    model.step()
+    da = (model.a1.tensor - alpha1[None, :]).sum(1)
+    assert float(((da - rows).abs() / rows.clamp_min(1.0)).max()) < 2e-5
+    db = (model.b1.tensor - beta1[None, :]).sum(1)
+    assert float(((db - cols).abs() / cols.clamp_min(1.0)).max()) < 2e-5
+    for name in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2'):
+        t = getattr(model, name).tensor
+        assert torch.isfinite(t).all() and float(t.min()) >= 1e-15, name
+    del model, ct, Zi, Zj
+    torch.cuda.empty_cache()
+
+
+def test_config3_zi_full_size_properties():
+    """BASELINE.json configs[2] (ZI-pCMF, 100,000 x 20,000, K = 50) at full size: one sweep keeps
+    the conservation property (D_hat = 1 at every non-zero, zigap.py:135), p_d carries the
+    overrides of zigap.py:133-135 exactly, pi_d = mean_i p_d (zigap.py:158)."""
+    from oriana_amd import engine
+    from oriana_amd.models import ZIGaP
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K = 100000, 20000, 50
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip('needs ~40 GB of free HBM')
+    gen = SyntheticCounts(n, m, K, seed=6234, device='cuda', zero_inflation_level=0.1)
+    chunk, rows, cols = _chunk_sums(gen, n, m)
+    ct = engine.CountTiles.from_chunks(n, m, chunk, 8192, 'cuda')
+    a1, b1 = gen.initial_shapes()
+    model = ZIGaP(ct, k=K, init=(a1, b1), device='cuda', reference_quirks=False)
+    alpha1 = model.alpha1.tensor.clone()
+    model.step()
+    da = (model.a1.tensor - alpha1[None, :]).sum(1)
+    assert float(((da - rows).abs() / rows.clamp_min(1.0)).max()) < 2e-5
+    p_d = model.p_d.tensor
+    assert float(p_d.min()) >= 0.0 and float(p_d.max()) <= 1.0
+    # the override at the non-zeros, checked on a slab against the generator's own X
+    X = gen.chunk(0, 8192)
+    nz = X != 0
+    assert bool((p_d[:8192][nz] == 1.0 - 1e-10).all())
+    assert bool((model._D_hat[:8192][nz] == 1.0).all())
+    assert bool((p_d[:8192][~nz] < 1.0 - 1e-10).any())
+    pi_ref = p_d.mean(0)
+    assert float((model.pi_d.tensor - pi_ref).abs().max()) < 1e-12
+    for name in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'pi_d'):
+        assert torch.isfinite(getattr(model, name).tensor).all(), name
+    del model, ct
+    torch.cuda.empty_cache()
+
+
 def test_graph_replay_matches_eager():
     """A sweep captured in a hipGraph and replayed gives the eager sweeps' state."""
     g = load_golden(golden_files('gap_c1_rand.npz')[0])

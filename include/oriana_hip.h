@@ -247,7 +247,9 @@ int oriana_dropout_update(double *p_d, float *D_hat, const double *Lambda, const
 /* mask[(i / 32) * m + j] bit (i % 32) = (D[i, j] != 0); ceil(rows / 32) * m words. */
 int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, int64_t m, void *stream);
 /* The same update with Lambda = U_hat V_hat^T formed on the matrix cores inside the kernel (f64 MFMA),
- * so that Lambda never goes through HBM: U (n, K), V (m, K) f64 row-major, K <= 256. */
+ * so that Lambda never goes through HBM: U (n, K), V (m, K) f64 row-major, K <= 256.  p_d and D_hat
+ * are optional outputs (NULL: not stored) -- the models keep only D_hat resident and evaluate p_d on
+ * access from a snapshot of (U, V, pi_d). */
 int oriana_dropout_update_fused(double *p_d, float *D_hat, const double *U, const double *V, const double *pi_d,
                                 const uint32_t *nzmask, double *colsum, int64_t n, int64_t m, int64_t K,
                                 void *stream);
@@ -257,8 +259,11 @@ int oriana_dropout_update_fused(double *p_d, float *D_hat, const double *U, cons
  * `out` must be initialised (zeros for a plain product).  K <= 256. */
 int oriana_dense_times_factor(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
                               int trans, void *stream);
+/* either output may be NULL */
 int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
 int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);
+/* the same for a float32 matrix (D_hat, while p_d == D_hat exactly: zigap.py:77) */
+int oriana_colsum_wide_f32(double *out, const float *A, int64_t rows, int64_t m, void *stream);
 /* dq[i, k] = D[i, k], k < K: the columns the reference's zigap.py:94 reads (D_hat[i, k]). */
 int oriana_take_cols_f32(float *out, const float *D, int64_t rows, int64_t m, int64_t K, void *stream);
 

@@ -53,6 +53,7 @@ _SIGS = {
     'oriana_dropout_fix_nz': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, c_double, _P]),
     'oriana_mul_f64_f32': (c_int, [_P, _P, _P, _I, _P]),
     'oriana_colsum_wide_f64': (c_int, [_P, _P, _I, _I, _P]),
+    'oriana_colsum_wide_f32': (c_int, [_P, _P, _I, _I, _P]),
     'oriana_take_cols_f32': (c_int, [_P, _P, _I, _I, _I, _P]),
     'oriana_sparsity_update': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_threshold_f32': (c_int, [_P, _P, c_double, _I, _P]),

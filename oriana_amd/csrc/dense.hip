@@ -71,14 +71,26 @@ __global__ __launch_bounds__(256) void k_dropout_fix_nz(oriana_counts cm, double
             const int64_t jp = cb * TILE + rec.col;
             const int64_t i = cm.row_perm ? (int64_t)cm.row_perm[ip] : ip;
             const int64_t j = cm.col_perm ? (int64_t)cm.col_perm[jp] : jp;
-            p_d[i * cm.m + j] = one;
-            D_hat[i * cm.m + j] = (float)one;
+            if (p_d) p_d[i * cm.m + j] = one;
+            if (D_hat) D_hat[i * cm.m + j] = (float)one;
         }
     }
 }
 
 // out[j] += sum_i A[i,j] for a wide (rows, m) f64 matrix (pi_d = mean(p_d, axis=0), zigap.py:158)
 __global__ __launch_bounds__(256) void k_colsum_wide(double *__restrict__ out, const double *__restrict__ A,
+                                                     int64_t rows, int64_t m) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 256;
+    const int64_t r1 = (r0 + 256 < rows) ? r0 + 256 : rows;
+    double s = 0.0;
+    for (int64_t i = r0; i < r1; ++i) s += A[i * m + j];
+    atomicAdd(&out[j], s);
+}
+
+// the same for a float32 matrix (column sums of D_hat while p_d == D_hat exactly, zigap.py:77)
+__global__ __launch_bounds__(256) void k_colsum_wide_f32(double *__restrict__ out, const float *__restrict__ A,
                                                      int64_t rows, int64_t m) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
@@ -212,7 +224,7 @@ extern "C" int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, i
 }
 
 extern "C" int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream) {
-    if (!cm || !p_d || !D_hat) return ORIANA_EINVAL;
+    if (!cm || (!p_d && !D_hat)) return ORIANA_EINVAL;
     const int64_t nt = cm->nrb * cm->ncb;
     if (nt == 0 || cm->rslots == 0) return 0;
     hipLaunchKernelGGL(k_dropout_fix_nz, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, p_d, D_hat, value);
@@ -227,6 +239,19 @@ extern "C" int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows
     for (int64_t y0 = 0; y0 * 256 < rows; y0 += 65535) {
         const int64_t ny = ((rows + 255) / 256 - y0 < 65535) ? (rows + 255) / 256 - y0 : 65535;
         hipLaunchKernelGGL(k_colsum_wide, dim3((unsigned)((m + 255) / 256), (unsigned)ny), dim3(256), 0,
+                           (hipStream_t)stream, out, A + y0 * 256 * m, rows - y0 * 256, m);
+    }
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_colsum_wide_f32(double *out, const float *A, int64_t rows, int64_t m, void *stream) {
+    if (rows < 0 || m < 0) return ORIANA_EINVAL;
+    if (rows == 0 || m == 0) return 0;
+    if (!out || !A) return ORIANA_EINVAL;
+    for (int64_t y0 = 0; y0 * 256 < rows; y0 += 65535) {
+        const int64_t ny = ((rows + 255) / 256 - y0 < 65535) ? (rows + 255) / 256 - y0 : 65535;
+        hipLaunchKernelGGL(k_colsum_wide_f32, dim3((unsigned)((m + 255) / 256), (unsigned)ny), dim3(256), 0,
                            (hipStream_t)stream, out, A + y0 * 256 * m, rows - y0 * 256, m);
     }
     ORIANA_LAUNCH_CHECK();

@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p
 #else
                             {
 #endif
-                                p_d[off] = p;
-                                D_hat[off] = (float)p;
+                                if (p_d) p_d[off] = p;
+                                if (D_hat) D_hat[off] = (float)p;
                             }
                             csum += p;
                         }
@@ -361,7 +361,7 @@ extern "C" int oriana_dropout_update_fused(double *p_d, float *D_hat, const doub
                                            int64_t m, int64_t K, void *stream) {
     if (n < 0 || m < 0 || K < 0 || K > 256) return ORIANA_EINVAL;
     if (n == 0 || m == 0) return 0;
-    if (!p_d || !D_hat || !pi_d || (K > 0 && (!U || !V))) return ORIANA_EINVAL;
+    if ((!p_d && !D_hat && !colsum) || !pi_d || (K > 0 && (!U || !V))) return ORIANA_EINVAL;
     const int KS = (int)((K + 3) / 4);
     const int us = KS * 4 + 1;
     const size_t lds = (size_t)64 * us * sizeof(double);
@@ -371,7 +371,8 @@ extern "C" int oriana_dropout_update_fused(double *p_d, float *D_hat, const doub
         const int64_t slab = 65535LL * 256;
         for (int64_t r0 = 0; r0 < n; r0 += slab) {
             const int64_t rows = (n - r0 < slab) ? n - r0 : slab;
-            int rc = oriana_dropout_update_fused(p_d + r0 * m, D_hat + r0 * m, U + r0 * K, V, pi_d,
+            int rc = oriana_dropout_update_fused(p_d ? p_d + r0 * m : nullptr, D_hat ? D_hat + r0 * m : nullptr,
+                                                 U + r0 * K, V, pi_d,
                                                  nzmask ? nzmask + (r0 / 32) * m : nullptr, colsum, rows, m, K,
                                                  stream);
             if (rc) return rc;

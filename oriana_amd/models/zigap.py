@@ -16,7 +16,7 @@ import torch
 from .. import engine
 from .. import dist as odist
 from .._lib import call, ptr, stream_ptr
-from ..parameters import Parameter
+from ..parameters import Parameter, LazyParameter
 from .base import FactorModel
 
 __all__ = ['ZIGaP', 'SparseGaP', 'SparseZIGaP']
@@ -28,11 +28,11 @@ class _ZIMixin:
     def _init_zi(self):
         n, m, dev = self.n, self.m, self.device
         self.pi_d = Parameter(torch.zeros(m, dtype=torch.float64, device=dev))
-        # p_d = (X > 0) as float (zigap.py:77): exactly 1.0 at the non-zero counts
-        p_d = torch.zeros(n, m, dtype=torch.float64, device=dev)
+        # p_d = (X > 0) as float (zigap.py:77): exactly 1.0 at the non-zero counts, so D_hat holds it
+        # exactly and the float64 matrix is only evaluated on access (LazyParameter)
         self._D_hat = torch.zeros(n, m, dtype=torch.float32, device=dev)
-        call('oriana_dropout_fix_nz', self.counts.c_struct, ptr(p_d), ptr(self._D_hat), 1.0, stream_ptr())
-        self.p_d = Parameter(p_d)
+        call('oriana_dropout_fix_nz', self.counts.c_struct, None, ptr(self._D_hat), 1.0, stream_ptr())
+        self.p_d = LazyParameter((n, m), dev, lambda: self._D_hat.double())
         self._pd_sum = torch.zeros(m, dtype=torch.float64, device=dev)
         # bit mask of X != 0 (constant): lets the D update apply p_d[X != 0] = 1 - 1e-10 in its own pass
         self._nzmask = torch.zeros(((n + 31) // 32) * max(m, 1), dtype=torch.int32, device=dev)
@@ -44,19 +44,32 @@ class _ZIMixin:
         return self._D_hat.cpu().numpy()
 
     def _refresh_D_hat(self):
-        self._D_hat.copy_(self.p_d.tensor)              # Bernoulli.mean: float32 cast (bernoulli.py:45)
-        self._pd_sum_fresh = False
+        """Bernoulli.mean: float32 cast of p_d (bernoulli.py:45).  While p_d is not materialised it is,
+        by construction, what D_hat was cast from."""
+        if self.p_d.materialised:
+            self._D_hat.copy_(self.p_d.tensor)
+            self._pd_sum_fresh = False
 
     def _mstep_pi_d(self):
         """pi_d = mean(p_d, axis=0) (zigap.py:158), summed over the row shards.  The column sums
-        come for free from the D update of the same sweep; they are recomputed only when p_d was
-        set from outside (initialisation, load_state)."""
+        come for free from the D update of the same sweep; otherwise (initialisation, p_d written
+        from outside, two M-steps in a row) they are taken from whatever currently defines p_d."""
         if not self._pd_sum_fresh:
             self._pd_sum.zero_()
-            call('oriana_colsum_wide_f64', ptr(self._pd_sum), ptr(self.p_d.tensor), self.n, self.m, stream_ptr())
+            st = stream_ptr()
+            if self.p_d.materialised:
+                call('oriana_colsum_wide_f64', ptr(self._pd_sum), ptr(self.p_d.tensor), self.n, self.m, st)
+            elif self._pd_snap is None:                 # p_d == D_hat exactly (zigap.py:77)
+                call('oriana_colsum_wide_f32', ptr(self._pd_sum), ptr(self._D_hat), self.n, self.m, st)
+            else:                                       # re-evaluate the sums only, nothing is stored
+                U, V, pi_d = self._pd_snap
+                call('oriana_dropout_update_fused', None, None, ptr(U), ptr(V), ptr(pi_d), ptr(self._nzmask),
+                     ptr(self._pd_sum), self.n, self.m, self.k, st)
         self._pd_sum_fresh = False
         odist.all_reduce_sum(self._pd_sum, self.pg)
         torch.div(self._pd_sum, float(self.n_total), out=self.pi_d.tensor)
+
+    _pd_snap = None
 
     def _D_times(self, V):
         """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K), f64 MFMA."""
@@ -74,12 +87,21 @@ class _ZIMixin:
 
     def _update_D(self, V_for_d):
         """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat; one fused
-        kernel that also leaves the column sums of p_d for the pi_d M-step."""
+        kernel that stores D_hat and leaves the column sums of p_d for the pi_d M-step.  The float64
+        p_d itself is not stored: it is re-evaluated on access from a snapshot of the three inputs."""
         self._pd_sum.zero_()
-        call('oriana_dropout_update_fused', ptr(self.p_d.tensor), ptr(self._D_hat), ptr(self._U_hat),
-             ptr(V_for_d.contiguous()), ptr(self.pi_d.tensor), ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m,
-             self.k, stream_ptr())
+        V = V_for_d.contiguous()
+        call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
+             ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, self.k, stream_ptr())
         self._pd_sum_fresh = True
+        self._pd_snap = snap = (self._U_hat.clone(), V.clone(), self.pi_d.tensor.clone())
+        self.p_d.defer(lambda: self._evaluate_p_d(*snap))
+
+    def _evaluate_p_d(self, U, V, pi_d):
+        p_d = torch.empty(self.n, self.m, dtype=torch.float64, device=self.device)
+        call('oriana_dropout_update_fused', ptr(p_d), None, ptr(U), ptr(V), ptr(pi_d), ptr(self._nzmask), None,
+             self.n, self.m, self.k, stream_ptr())
+        return p_d
 
 
 class _SparseMixin:

@@ -168,6 +168,26 @@ int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag,
                  float *Zi, float *Zj, float *Zlog,
                  int64_t K, int variant, void *stream);
 
+/* ---- deviance / Frobenius metrics (base.py:58-87 with loglikelihood_X, sparse_zigap.py:44-51) --------
+ * The metrics split into sums over the stored (non-zero) entries, sums over the zero entries and closed
+ * forms of column sums (oriana_amd/models/base.py:_metric_terms spells the algebra out).
+ *   oriana_factor_cast_f32 : F (r, Kp) f32 = float32(E[row_index[i], :] (* mul)) -- with these factors
+ *                            oriana_row_pass leaves s_ij = x_ij / Lambda_ij in s_rs
+ *   oriana_metric_nnz      : out4 += { sum Lambda, sum x log Lambda, sum Lambda^2, sum x Lambda } over the stored
+ *                            entries (Lambda = x / s; entries with the NaN sentinel are recomputed in f64)
+ *   oriana_count_stats     : constants of X: per-gene sums and non-zero counts, sum (x log x - x), sum x^2
+ *   oriana_dropout_metric  : out2 += { sum log(pi_j exp(-Lambda_ij) + 1 - pi_j), sum Lambda_ij^2 } over the
+ *                            entries with X == 0 and round(D_hat) == 1 (the mask of base.py:60-61, 67);
+ *                            Lambda = U V^T on the f64 matrix cores, never stored
+ */
+int oriana_factor_cast_f32(float *F, const double *E, const float *mul, const int32_t *row_index,
+                           int64_t r, int64_t K, void *stream);
+int oriana_metric_nnz(const oriana_counts *cm, const float *s_rs, const double *U, const double *V,
+                      int64_t K, double *out4, void *stream);
+int oriana_count_stats(const oriana_counts *cm, double *colsum, double *colnnz, double *out2, void *stream);
+int oriana_dropout_metric(double *out2, const float *D_hat, const double *U, const double *V, const double *pi_d,
+                          const uint32_t *nzmask, int64_t n, int64_t m, int64_t K, void *stream);
+
 /* ---- stateless drop-ins with the reference's exact signatures (outputs first) ------------------
  * One entry per loop nest, arguments in the reference's order, all matrices dense C-contiguous f32
  * on the device: X, D_hat (n, m); log_U_hat and the row-side output (n, K); log_V_hat, S_tilde, S_hat

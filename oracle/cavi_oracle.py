@@ -314,6 +314,60 @@ class _OracleModel:
             if self.sparse:
                 self.S_hat = S_hat_new
 
+    # ---- metrics (base.py:58-87 with loglikelihood_X, sparse_zigap.py:44-51) ----
+    # The reference defines loglikelihood_X on SparseZIGaP only, so the deviances raise AttributeError
+    # on the other three classes; here the absent nodes read as constants (pi_d = 1, D_hat = 1,
+    # S_hat = 1), which is what the SparseZIGaP formulas reduce to.  float64 throughout: the reference
+    # stores the per-entry terms in `np.empty_like(X)` (sparse_zigap.py:45) and therefore truncates
+    # them when X is an integer array; with a float X it computes exactly this.
+    def _metric_inputs(self):
+        pi_d = self.pi_d if self.zi else np.ones(self.p)
+        D = np.round(self.D_hat) if self.zi else np.ones((self.n, self.p))           # base.py:60
+        V = self.V_hat * self.S_hat if self.sparse else self.V_hat                   # base.py:65
+        return pi_d, D, np.dot(self.U_hat, V.T)                                      # base.py:66
+
+    def loglikelihood_X(self, Lambda, pi_d):
+        """sparse_zigap.py:44-51"""
+        X = self.X.astype(np.float64)
+        ret = np.empty_like(X)
+        pi = np.repeat(pi_d[np.newaxis, ...], X.shape[0], axis=0)
+        z = X == 0
+        with np.errstate(all='ignore'):
+            ret[z] = np.log(pi[z] * np.exp(-Lambda[z]) + (1 - pi[z]))
+            ret[~z] = np.log(pi[~z]) - Lambda[~z] + X[~z] * np.log(Lambda[~z])
+        return ret.sum()
+
+    def reconstruction_deviance(self):
+        """base.py:58-69"""
+        pi_d, D, Lambda = self._metric_inputs()
+        mask = D == 0
+        assert not mask.all()
+        X = self.X.astype(np.float64)
+        ll_X_given_X = self.loglikelihood_X(X, pi_d)
+        Lambda[mask] = 0
+        ll_X_given_UV = self.loglikelihood_X(Lambda, pi_d)
+        return -2. * (ll_X_given_UV - ll_X_given_X)
+
+    def explained_deviance(self):
+        """base.py:71-82, called after reconstruction_deviance (experiments/clustering.py:26-27):
+        the U, V, D node buffers are the ones that call left behind."""
+        pi_d, D, Lambda = self._metric_inputs()
+        mask = D == 0
+        assert not mask.all()
+        X = self.X.astype(np.float64)
+        ll_X_given_X = self.loglikelihood_X(X, pi_d)
+        mean = np.repeat(X.mean(axis=0)[np.newaxis, ...], X.shape[0], axis=0)
+        ll_X_given_X_mean = self.loglikelihood_X(mean, pi_d)
+        Lambda[mask] = 0
+        ll_X_given_UV = self.loglikelihood_X(Lambda, pi_d)
+        return (ll_X_given_UV - ll_X_given_X_mean) / (ll_X_given_X - ll_X_given_X_mean)
+
+    def frobenius_norm(self):
+        """base.py:84-87 on the UV buffer the deviance calls leave behind (Lambda with the mask applied)."""
+        _, D, Lambda = self._metric_inputs()
+        Lambda[D == 0] = 0
+        return np.sqrt(((Lambda.flatten() - self.X.astype(np.float64).flatten()) ** 2.).sum())
+
     def state(self):
         keys = ['alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2',
                 'U_hat', 'V_hat', 'log_U_hat', 'log_V_hat']

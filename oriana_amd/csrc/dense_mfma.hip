@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void k_dense_times_factor(double *__restrict__
 // lives in LDS (A operand), V_hat fragments come from L2 four reduction steps ahead of their use
 // (B operand), the reduction runs over K.  nzmask: oriana_nzmask_f32 layout, two words per lane
 // cover the 64 rows of a sub-block.
+// MODE 1 (metrics, base.py:58-87 with sparse_zigap.py:44-51): nothing is stored; over the entries with
+// X == 0 and round(D_hat) == 1 the kernel sums log(pi_j exp(-Lambda) + 1 - pi_j) and Lambda^2 into
+// colsum[0], colsum[1] (one pair of f64 atomics per wave); D_hat is read.
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p_d, float *__restrict__ D_hat,
                                                        const double *__restrict__ U, const double *__restrict__ V,
                                                        const double *__restrict__ pi_d,
@@ -246,7 +250,29 @@ __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p
             const double pi = cur.pi;
             const uint32_t w0 = cur.w0, w1 = cur.w1;
             fetch(cur, (ct == 3) ? i0 + 64 : i0, (ct + 1) & 3);
-            if (jok) {
+            if (MODE == 1) {
+                if (jok) {
+                    int64_t off = (i0 + g) * m + j;
+                    const int64_t step = 4 * m;
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const uint32_t w = (rt < 2) ? w0 : w1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int bit = (rt & 1) * 16 + g + 4 * r;
+                            const int64_t i = i0 + rt * 16 + g + 4 * r;
+                            asm volatile("" : "+v"(off));
+                            if (i < n && !((w >> bit) & 1u) && D_hat[off] > 0.5f) {
+                                const double lam = acc[rt][r];
+                                cs[0] += log(pi * exp(-lam) + (1.0 - pi));
+                                cs[1] += lam * lam;
+                            }
+                            off += step;
+                        }
+                    }
+                }
+            } else if (jok) {
                 const double lg = logit_f64(pi);
                 double csum = 0.0;
                 // element (rt, r) sits in row i0 + g + 4 (4 rt + r): one running offset, 4 m per step (kept
@@ -288,7 +314,14 @@ __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p
             }
         }
     }
-    if (colsum) {
+    if (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double v = cs[c];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) atomicAdd(&colsum[c], v);
+        }
+    } else if (colsum) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             double v = cs[ct];
@@ -356,34 +389,43 @@ extern "C" int oriana_dense_times_factor(double *out, const float *D, const doub
     return 0;
 }
 
+template <int MODE>
+static int launch_dropout_fused(double *p_d, float *D_hat, const double *U, const double *V, const double *pi_d,
+                                const uint32_t *nzmask, double *colsum, int64_t n, int64_t m, int64_t K,
+                                void *stream) {
+    const int KS = (int)((K + 3) / 4);
+    const int us = KS * 4 + 1;
+    const size_t lds = (size_t)64 * us * sizeof(double);
+    const int64_t ncb = (m + 255) / 256;
+    const int64_t slab = 65535LL * 256;                  // row blocks in slabs of 65535 * 256 rows
+    if (lds > 64 * 1024)
+        ORIANA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dropout_fused<MODE>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int64_t r0 = 0; r0 < n; r0 += slab) {
+        const int64_t rows = (n - r0 < slab) ? n - r0 : slab;
+        hipLaunchKernelGGL(k_dropout_fused<MODE>, dim3((unsigned)ncb, (unsigned)((rows + 255) / 256)), dim3(256), lds,
+                           (hipStream_t)stream, p_d ? p_d + r0 * m : nullptr, D_hat ? D_hat + r0 * m : nullptr,
+                           U + r0 * K, V, pi_d, nzmask ? nzmask + (r0 / 32) * m : nullptr, colsum, rows, m, (int)K, KS,
+                           us);
+    }
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int oriana_dropout_update_fused(double *p_d, float *D_hat, const double *U, const double *V,
                                            const double *pi_d, const uint32_t *nzmask, double *colsum, int64_t n,
                                            int64_t m, int64_t K, void *stream) {
     if (n < 0 || m < 0 || K < 0 || K > 256) return ORIANA_EINVAL;
     if (n == 0 || m == 0) return 0;
     if ((!p_d && !D_hat && !colsum) || !pi_d || (K > 0 && (!U || !V))) return ORIANA_EINVAL;
-    const int KS = (int)((K + 3) / 4);
-    const int us = KS * 4 + 1;
-    const size_t lds = (size_t)64 * us * sizeof(double);
-    const int64_t nrb = (n + 255) / 256, ncb = (m + 255) / 256;
-    if (nrb > 65535) {
-        // row blocks in slabs of 65535 * 256 rows
-        const int64_t slab = 65535LL * 256;
-        for (int64_t r0 = 0; r0 < n; r0 += slab) {
-            const int64_t rows = (n - r0 < slab) ? n - r0 : slab;
-            int rc = oriana_dropout_update_fused(p_d ? p_d + r0 * m : nullptr, D_hat ? D_hat + r0 * m : nullptr,
-                                                 U + r0 * K, V, pi_d,
-                                                 nzmask ? nzmask + (r0 / 32) * m : nullptr, colsum, rows, m, K,
-                                                 stream);
-            if (rc) return rc;
-        }
-        return 0;
-    }
-    if (lds > 64 * 1024)
-        ORIANA_HIP_CHECK(hipFuncSetAttribute((const void *)k_dropout_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)lds));
-    hipLaunchKernelGGL(k_dropout_fused, dim3((unsigned)ncb, (unsigned)nrb), dim3(256), lds, (hipStream_t)stream, p_d,
-                       D_hat, U, V, pi_d, nzmask, colsum, n, m, (int)K, KS, us);
-    ORIANA_LAUNCH_CHECK();
-    return 0;
+    return launch_dropout_fused<0>(p_d, D_hat, U, V, pi_d, nzmask, colsum, n, m, K, stream);
+}
+
+extern "C" int oriana_dropout_metric(double *out2, const float *D_hat, const double *U, const double *V,
+                                     const double *pi_d, const uint32_t *nzmask, int64_t n, int64_t m, int64_t K,
+                                     void *stream) {
+    if (n < 0 || m < 0 || K < 0 || K > 256) return ORIANA_EINVAL;
+    if (n == 0 || m == 0) return 0;
+    if (!out2 || !D_hat || !pi_d || !nzmask || (K > 0 && (!U || !V))) return ORIANA_EINVAL;
+    return launch_dropout_fused<1>(nullptr, const_cast<float *>(D_hat), U, V, pi_d, nzmask, out2, n, m, K, stream);
 }

@@ -240,6 +240,108 @@ class FactorModel:
     def update_variational_parameters(self):
         raise NotImplementedError
 
+    # ---- metrics (reference base.py:58-87; loglikelihood_X: sparse_zigap.py:44-51) --------------------
+    # The reference defines loglikelihood_X on SparseZIGaP only (the deviances raise AttributeError on
+    # the other classes); here the absent nodes read as the constants the formulas reduce to
+    # (pi_d = 1, D = 1, S_hat = 1).  With N = {X != 0}, Z = {X == 0}, M = {round(D_hat) == 0} (M never
+    # meets N: D_hat = 1 at the non-zeros), Lambda = U_hat (S_hat * V_hat)^T and mu_j = mean_i X_ij:
+    #   ll(X | X)      = sum_j nnz_j log pi_j + sum_N (x log x - x)                  (zeros give log 1 = 0)
+    #   ll(X | Lambda) = sum_{Z - M} log(pi_j e^-Lambda + 1 - pi_j) + sum_j nnz_j log pi_j
+    #                    - sum_N Lambda + sum_N x log Lambda
+    #   ll(X | mu)     = sum_j (n - nnz_j) log(pi_j e^-mu_j + 1 - pi_j) + sum_j nnz_j (log pi_j - mu_j)
+    #                    + sum_j colsum_j log mu_j
+    # The sums over N come from the responsibility kernels (metrics.hip), the sum over Z - M from the
+    # f64-MFMA kernel of the D update in metric mode (or, without a D node, from column sums:
+    # sum_Z Lambda = sum_k (sum_i U_ik)(sum_j V_jk) - sum_N Lambda).  Float64 semantics: what the
+    # reference computes for a float X (for an integer X it truncates every term, sparse_zigap.py:45).
+    def _count_constants(self):
+        """Per-gene sums / non-zero counts of X and sum_N (x log x - x), sum_N x^2 (all-reduced, cached)."""
+        if getattr(self, '_xconst', None) is None:
+            dev = self.device
+            colsum = torch.zeros(self.m, dtype=torch.float64, device=dev)
+            colnnz = torch.zeros(self.m, dtype=torch.float64, device=dev)
+            out2 = torch.zeros(2, dtype=torch.float64, device=dev)
+            call('oriana_count_stats', self.counts.c_struct, ptr(colsum), ptr(colnnz), ptr(out2), stream_ptr())
+            for t in (colsum, colnnz, out2):
+                odist.all_reduce_sum(t, self.pg)
+            self._xconst = (colsum, colnnz, out2)
+        return self._xconst
+
+    def _metric_terms(self):
+        ct, K, n, m, dev = self.counts, self.k, self.n, self.m, self.device
+        st = stream_ptr()
+        U, V = self._U_hat, self._effective_V().contiguous()
+        ws = self._ws
+        FU, FV = ws.extra('MU', n), ws.extra('MV', m)
+        call('oriana_factor_cast_f32', ptr(FU), ptr(U), None, ptr(ct.row_perm), n, K, st)
+        call('oriana_factor_cast_f32', ptr(FV), ptr(V), None, ptr(ct.col_perm), m, K, st)
+        if ws.s_rs is None:
+            ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=dev)
+        ws.tile_flag.zero_()
+        # with these factors the row pass leaves s = x / Lambda in the row-side slots
+        call('oriana_row_pass', ct.c_struct, ptr(FU), ptr(FV), None, ptr(ws.R), ptr(ws.s_cs), None, ptr(ws.s_rs),
+             ptr(ws.tile_flag), K, st)
+        nz = torch.zeros(4, dtype=torch.float64, device=dev)      # sum Lambda, sum x log Lambda, sum Lambda^2, sum x Lambda
+        call('oriana_metric_nnz', ct.c_struct, ptr(ws.s_rs), ptr(U), ptr(V), K, ptr(nz), st)
+        zz = torch.zeros(2, dtype=torch.float64, device=dev)      # over Z - M: sum log(pi e^-Lambda + 1 - pi), sum Lambda^2
+        if self.zi:
+            call('oriana_dropout_metric', ptr(zz), ptr(self._D_hat), ptr(U), ptr(V), ptr(self.pi_d.tensor),
+                 ptr(self._nzmask), n, m, K, st)
+            odist.all_reduce_sum(zz, self.pg)
+            odist.all_reduce_sum(nz, self.pg)
+        else:
+            su = U.sum(0)
+            gram_u = U.t() @ U
+            packed = torch.cat([nz, su, gram_u.reshape(-1)])
+            odist.all_reduce_sum(packed, self.pg)
+            nz, su, gram_u = packed[:4], packed[4:4 + K], packed[4 + K:].reshape(K, K)
+            all_lam = (su * V.sum(0)).sum()
+            all_lam2 = (gram_u * (V.t() @ V)).sum()
+            zz[0] = -(all_lam - nz[0])
+            zz[1] = all_lam2 - nz[2]
+        return nz, zz
+
+    def _log_pi(self):
+        if self.zi:
+            return torch.log(self.pi_d.tensor), self.pi_d.tensor
+        one = torch.ones(self.m, dtype=torch.float64, device=self.device)
+        return torch.zeros_like(one), one
+
+    def _loglikelihoods(self):
+        colsum, colnnz, xc = self._count_constants()
+        nz, zz = self._metric_terms()
+        lpi, pi = self._log_pi()
+        has = colnnz > 0
+        nnz_lpi = torch.where(has, colnnz * lpi, torch.zeros_like(lpi)).sum()
+        ll_x = nnz_lpi + xc[0]
+        ll_uv = zz[0] + nnz_lpi - nz[0] + nz[1]
+        ntot = float(self.n_total)
+        mu = colsum / ntot
+        zero_term = (ntot - colnnz) * torch.log(pi * torch.exp(-mu) + (1.0 - pi))
+        nz_term = torch.where(has, colnnz * (lpi - mu) + colsum * torch.log(torch.where(has, mu, torch.ones_like(mu))),
+                              torch.zeros_like(mu))
+        ll_mean = (zero_term + nz_term).sum()
+        return float(ll_x), float(ll_uv), float(ll_mean), nz, zz, xc
+
+    def reconstruction_deviance(self):
+        """-2 (ll(X | U_hat V_hat^T) - ll(X | X)), reference base.py:58-69."""
+        ll_x, ll_uv, _, _, _, _ = self._loglikelihoods()
+        return -2.0 * (ll_uv - ll_x)
+
+    def explained_deviance(self):
+        """(ll(X | U_hat V_hat^T) - ll(X | mean)) / (ll(X | X) - ll(X | mean)), reference base.py:71-82
+        evaluated on the current expectations (the reference reads the node buffers its own
+        reconstruction_deviance call left behind, experiments/clustering.py:26-27)."""
+        ll_x, ll_uv, ll_mean, _, _, _ = self._loglikelihoods()
+        return (ll_uv - ll_mean) / (ll_x - ll_mean)
+
+    def frobenius_norm(self):
+        """|| Lambda - X ||_F with Lambda = U_hat V_hat^T, zeroed where round(D_hat) == 0 (reference
+        base.py:84-87 on the UV buffer the deviance calls leave behind)."""
+        _, _, _, nz, zz, xc = self._loglikelihoods()
+        # sum_N (Lambda - x)^2 + sum_{Z - M} Lambda^2
+        return float(torch.sqrt(torch.clamp(nz[2] - 2.0 * nz[3] + xc[1] + zz[1], min=0.0)))
+
     # ---- state I/O (tests, checkpoints) ---------------------------------------------------------------
     _PARAMS = ('alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_d', 'p_d', 'pi_s', 'p_s')
 

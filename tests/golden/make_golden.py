@@ -118,6 +118,33 @@ def run_case(oriana, name, n, m, k, use_factors, seed, sweeps=(1, 2, 3, 10)):
     return out
 
 
+def metrics_case(oriana, n, m, k, seed, sweeps=3):
+    """reconstruction_deviance / explained_deviance / frobenius_norm of the reference (base.py:58-87;
+    only SparseZIGaP defines loglikelihood_X, sparse_zigap.py:44-51), called in the order of
+    experiments/clustering.py:26-27, once with the generator's integer X (the per-entry terms are then
+    truncated by `np.empty_like(X)`, sparse_zigap.py:45) and once with the same X as float64."""
+    from oriana.singlecell import CountMatrix, generate_factor_matrices
+    out = {}
+    for tag, dtype in (('int', np.int64), ('float', np.float64)):
+        np.random.seed(seed)
+        X, _, _, _ = generate_factor_matrices(n, m, k)
+        np.random.seed(seed + 1)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = oriana.models.SparseZIGaP(CountMatrix(np.asarray(X).astype(dtype)), k=k, use_factors=False)
+            out['s0/a1'] = np.array(model.a1[:]); out['s0/b1'] = np.array(model.b1[:])
+            for _ in range(sweeps):
+                model.step()
+            snapshot(model, 's%d' % sweeps, out)
+            out['X'] = np.asarray(X, dtype=np.int64)
+            out['metrics_%s/reconstruction_deviance' % tag] = np.array(model.reconstruction_deviance())
+            out['metrics_%s/explained_deviance' % tag] = np.array(model.explained_deviance())
+            out['metrics_%s/frobenius_norm' % tag] = np.array(model.frobenius_norm())
+    out['meta/k'] = np.array(k); out['meta/sweeps'] = np.array(sweeps); out['meta/tau'] = np.array(0.5)
+    out['meta/name'] = np.array('SparseZIGaP')
+    return out
+
+
 def tables(oriana):
     from oriana.utils import digamma, inverse_digamma, sigmoid, logit
     out = {}
@@ -153,5 +180,18 @@ def main():
                 print('wrote', fn, 'zeros=%.3f' % (out['X'] == 0).mean())
 
 
+def main_metrics():
+    oriana = import_reference()
+    for tag, (n, m, k, seed) in {'c1': (200, 80, 5, 0), 'odd': (257, 131, 7, 100)}.items():
+        out = metrics_case(oriana, n, m, k, seed)
+        fn = 'metrics_sparsezigap_%s.npz' % tag
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        print('wrote', fn, {k: float(v) for k, v in out.items() if k.startswith('metrics_')})
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':
+        main_metrics()          # only the metrics fixtures (the sweep fixtures are left as they are)
+    else:
+        main()
+        main_metrics()

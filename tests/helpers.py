@@ -20,7 +20,9 @@ KEY_RTOL = {'p_d': 1e-4, 'p_s': 1e-4, 'pi_d': 1e-4, 'pi_s': 1e-4, 'S_hat': 1e-4}
 
 
 def golden_files(pattern='*_*.npz'):
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if not f.endswith('tables.npz'))
+    skip_metrics = not pattern.startswith('metrics_')
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern))
+                  if not f.endswith('tables.npz') and not (skip_metrics and os.path.basename(f).startswith('metrics_')))
 
 
 def load_golden(path):

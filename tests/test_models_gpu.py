@@ -164,6 +164,61 @@ def test_config2_full_size_properties():
     assert err_colrel(Zj.cpu().numpy(), rZj) < 5e-5
 
 
+# ---- metrics (reference base.py:58-87, sparse_zigap.py:44-51) -------------------------------------------
+
+@pytest.mark.parametrize('path', golden_files('metrics_*.npz'), ids=os.path.basename)
+def test_metrics_match_reference(path):
+    """reconstruction_deviance / explained_deviance / frobenius_norm of the HIP SparseZIGaP started from
+    the reference's own state after 3 sweeps, against the values the reference returned (float64 X)."""
+    import oriana_amd.models as M
+    g = load_golden(path)
+    sw = int(g['meta/sweeps'])
+    model = M.SparseZIGaP(g['X'], k=int(g['meta/k']), tau=float(g['meta/tau']), init=(g['s0/a1'], g['s0/b1']))
+    model.load_state(state_of(g, 's%d' % sw))
+    rd = model.reconstruction_deviance()
+    ed = model.explained_deviance()
+    fn = model.frobenius_norm()
+    # float32 factors feed the per-entry Lambda (1e-7 each, summed in float64): 1e-5 on the deviance,
+    # which is itself a difference of two log-likelihoods ~50x larger
+    assert abs(rd / float(g['metrics_float/reconstruction_deviance']) - 1.0) < 1e-5
+    assert abs(ed - float(g['metrics_float/explained_deviance'])) < 1e-6
+    assert abs(fn / float(g['metrics_float/frobenius_norm']) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['GaP', 'ZIGaP', 'SparseGaP', 'SparseZIGaP'])
+def test_metrics_match_oracle(name):
+    """All four models (the reference only defines the metrics on SparseZIGaP; the absent nodes read as
+    constants, see FactorModel._metric_terms) against the dense NumPy oracle after two sweeps, on a
+    multi-tile shape with empty genes and empty cells."""
+    import oriana_amd.models as M
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(17)
+    n, m, K = 600, 530, 12
+    X = rng.poisson(rng.gamma(0.4, 4.0, size=(n, m))).astype(np.float64) * (rng.random((n, m)) < 0.25)
+    X[:, 7] = 0
+    X[11, :] = 0
+    a1 = rng.gamma(1.0, 1.0, size=(n, K)); b1 = rng.gamma(1.0, 1.0, size=(m, K))
+    G = getattr(M, name)(X, k=K, init=(a1, b1), reference_quirks=True)
+    O = co.MODELS[name](X, K, a1, b1)
+    for _ in range(2):
+        G.step(); O.step()
+    O.load_state(G.state())                     # same state: compare the metric code, not the sweeps
+    if O.zi:
+        O.D_hat = co.bernoulli_mean(O.p_d)
+    if O.sparse:
+        O.S_hat = co.bernoulli_mean(O.p_s)
+    rd, ed, fn = G.reconstruction_deviance(), G.explained_deviance(), G.frobenius_norm()
+    assert abs(rd / O.reconstruction_deviance() - 1.0) < 1e-5
+    assert abs(ed - O.explained_deviance()) < 1e-6
+    assert abs(fn / O.frobenius_norm() - 1.0) < 1e-6
+    # the metrics leave the model untouched
+    before = G.state()
+    G.reconstruction_deviance()
+    after = G.state()
+    for k in before:
+        assert np.array_equal(before[k], after[k], equal_nan=True), k
+
+
 def _chunk_sums(gen, n, m):
     """chunk function that also accumulates the exact row / column sums of X (first visit only)."""
     rows = torch.zeros(n, dtype=torch.float64, device='cuda')

@@ -114,3 +114,25 @@ def test_empty_and_zero_inputs():
     # den == 0 guard (gap.py:76): all exponentials underflow -> contributions are 0, not NaN
     co.zq_gap(Zi, Zj, lu - 1e15, lv, np.ones((4, 5), np.float32))
     assert not Zi.any() and not Zj.any()
+
+
+# ---- metrics (base.py:58-87, sparse_zigap.py:44-51) ---------------------------------------------------
+
+@pytest.mark.parametrize('path', golden_files('metrics_*.npz'), ids=os.path.basename)
+def test_oracle_metrics_match_reference(path):
+    """The oracle's deviances / Frobenius norm on the reference's own state after 3 sweeps against the
+    values the reference returned (float64 X); the reference's integer-X values differ only by the
+    truncation of the per-entry terms (sparse_zigap.py:45)."""
+    g = load_golden(path)
+    sw = int(g['meta/sweeps'])
+    O = co.MODELS['SparseZIGaP'](g['X'], int(g['meta/k']), g['s0/a1'], g['s0/b1'], tau=float(g['meta/tau']))
+    O.load_state(state_of(g, 's%d' % sw))
+    O.D_hat = co.bernoulli_mean(O.p_d)
+    O.S_hat = co.bernoulli_mean(O.p_s)
+    rd, ed, fn = O.reconstruction_deviance(), O.explained_deviance(), O.frobenius_norm()
+    assert abs(rd / float(g['metrics_float/reconstruction_deviance']) - 1.0) < 1e-9
+    assert abs(ed - float(g['metrics_float/explained_deviance'])) < 1e-9
+    assert abs(fn / float(g['metrics_float/frobenius_norm']) - 1.0) < 1e-9
+    # truncation moves the reference's integer-X value by less than one unit per entry
+    assert abs(rd - float(g['metrics_int/reconstruction_deviance'])) < 2.0 * g['X'].size
+    assert abs(ed - float(g['metrics_int/explained_deviance'])) < 1e-3

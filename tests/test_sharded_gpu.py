@@ -43,6 +43,7 @@ def _worker(rank, world, port, path, name, out):
                     process_group=dist.group.WORLD)
         assert model.n_total == X.shape[0]
         model.fit(2)
+        metrics = np.array([model.reconstruction_deviance(), model.explained_deviance(), model.frobenius_norm()])
         st = model.state()
         rows = {k: st[k] for k in ('a1', 'a2', 'U_hat') if k in st}
         if 'p_d' in st:
@@ -54,6 +55,7 @@ def _worker(rank, world, port, path, name, out):
             for k in ('b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'pi_d', 'p_s', 'pi_s'):
                 if k in st:
                     full[k] = st[k]
+            full['metrics'] = metrics
             np.savez(out, **full)
         dist.barrier()
         torch.cuda.synchronize()
@@ -84,5 +86,10 @@ def test_two_ranks_match_one(tmp_path, name, fn):
     # sigmoid (helpers.sparsity_tolerance), so they get an absolute 1e-3 here -- this test is about
     # the sharding logic, the conditioning is covered by tests/test_models_gpu.py.
     for k in got.files:
+        if k == 'metrics':
+            continue
         tol = 1e-3 if k in ('p_d', 'p_s', 'pi_d', 'pi_s') else 2e-5
         assert err_colrel(got[k], ref[k]) < tol, k
+    # the deviances / Frobenius norm are sums over the row shards, all-reduced
+    ref_m = np.array([single.reconstruction_deviance(), single.explained_deviance(), single.frobenius_norm()])
+    np.testing.assert_allclose(got['metrics'], ref_m, rtol=1e-4)

@@ -38,6 +38,11 @@ class _Buffer:
         return self._getter()[key].detach().cpu().numpy()
 
 
+def _is_sparse_input(c):
+    import scipy.sparse as sp
+    return sp.issparse(c) or (getattr(c, 'is_sparse', False) is True)
+
+
 class FactorModel:
     """Base class (reference models/base.py:13-56).
 
@@ -71,6 +76,10 @@ class FactorModel:
         X_host = None
         if isinstance(cmatrix, engine.CountTiles):
             self.counts = cmatrix
+        elif _is_sparse_input(cmatrix):
+            A = cmatrix._sparse if hasattr(cmatrix, '_sparse') else cmatrix
+            X_host = A                     # the host-side initialisation reads it in sparse form
+            self.counts = engine.CountTiles.from_scipy(A, self.device)
         else:
             X = cmatrix.as_array() if hasattr(cmatrix, 'as_array') else cmatrix
             if not isinstance(X, torch.Tensor):

@@ -15,6 +15,11 @@ import numpy as np
 __all__ = ['reference_initial_shapes']
 
 
+def _is_sparse(X):
+    import scipy.sparse as sp
+    return sp.issparse(X)
+
+
 def reference_initial_shapes(model_name, X, k, use_factors):
     n, m = X.shape
     zi = model_name in ('ZIGaP', 'SparseZIGaP')
@@ -37,7 +42,8 @@ def reference_initial_shapes(model_name, X, k, use_factors):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         nmf = NMF(n_components=k)                   # base.py:38
-        W = nmf.fit_transform(np.asarray(X))        # base.py:39
+        # base.py:39 (a SciPy sparse X goes to scikit-learn as it is: same factorisation, no dense copy)
+        W = nmf.fit_transform(X if _is_sparse(X) else np.asarray(X))
         H = nmf.components_.T                       # base.py:40
     if use_factors:
         a1, b1 = W, H                               # gap.py:49-50, 59-60

@@ -85,3 +85,35 @@ def test_shard_rows_bookkeeping():
     assert shard_rows(1000000, 7, 8) == (875000, 1000000)
     with pytest.raises(ValueError):
         shard_rows(10, 3, 3)
+
+
+def test_count_matrix_surface(tmp_path):
+    """oriana_amd.singlecell.CountMatrix keeps the reference surface (cmatrix.py:12-115) and adds
+    SciPy-sparse input."""
+    import numpy as np
+    import pandas as pd
+    import scipy.sparse as sp
+    from oriana_amd.singlecell import CountMatrix
+    from oriana_amd.exceptions import DatatypeException
+    X = np.arange(12).reshape(4, 3) % 4
+    c = CountMatrix(X)
+    assert c.shape == (4, 3) and np.array_equal(c.as_array(), X)
+    assert np.array_equal(c.T.as_array(), X.T)
+    assert sp.isspmatrix_csc(c.as_sparse_matrix()) and sp.isspmatrix_csr(c.as_sparse_matrix('csr'))
+    assert np.array_equal(c.as_sparse_matrix().toarray(), X)
+    df = pd.DataFrame(X, index=['a', 'b', 'c', 'd'], columns=['g0', 'g1', 'g2'])
+    path = str(tmp_path / 'x.csv')
+    df.to_csv(path)
+    d = CountMatrix.from_csv(path)
+    assert list(d.col_names) == ['g0', 'g1', 'g2'] and list(d.row_names) == ['a', 'b', 'c', 'd']
+    assert np.array_equal(d.as_array(), X)
+    assert np.array_equal(d['g1'].values, X[:, 1])
+    sub = d.filter_rows(['b', 'd'], inplace=False)
+    assert sub.shape == (2, 3) and d.shape == (4, 3)
+    d.filter_rows(['a'])
+    assert d.shape == (1, 3)
+    s = CountMatrix(sp.coo_matrix(X))
+    assert s.is_sparse and s.shape == (4, 3) and np.array_equal(s.as_array(), X)
+    assert np.array_equal(s.T.as_array(), X.T)
+    with pytest.raises(DatatypeException):
+        CountMatrix([[1, 2], [3, 4]])

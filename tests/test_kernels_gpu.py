@@ -308,6 +308,29 @@ def test_zigap_dropin_corrected_index_and_edges(eng):
                                          torch.ones(4, 3, device='cuda'))
 
 
+def test_pack_from_scipy_matches_dense(eng):
+    """CountTiles.from_scipy (row chunks of a CSR matrix expanded on the device) builds the same
+    tiles as from_dense; a model built from a sparse CountMatrix steps like the dense one."""
+    import scipy.sparse as sp
+    import oriana_amd.models as M
+    from oriana_amd.singlecell import CountMatrix
+    rng = np.random.default_rng(23)
+    n, m, K = 700, 300, 6
+    X = _rand_counts(rng, n, m, 0.15).astype(np.float32)
+    X[300:560] = 0                                            # an empty row block
+    A = sp.csr_matrix(X)
+    ct_d = eng.CountTiles.from_dense(X, 'cuda')
+    ct_s = eng.CountTiles.from_scipy(A, 'cuda', chunk_rows=256)
+    assert ct_s.nnz == ct_d.nnz == A.nnz
+    assert np.array_equal(ct_s.to_dense(), X) and np.array_equal(ct_d.to_dense(), X)
+    a1 = rng.gamma(1.0, 1.0, size=(n, K)); b1 = rng.gamma(1.0, 1.0, size=(m, K))
+    g_d = M.GaP(X, k=K, init=(a1, b1)); g_s = M.GaP(CountMatrix(A), k=K, init=(a1, b1))
+    g_d.fit(2); g_s.fit(2)
+    for k, v in g_d.state().items():
+        assert err_colrel(g_s.state()[k], v) < 1e-6, k
+    assert sp.issparse(CountMatrix(A).as_sparse_matrix('csr'))
+
+
 # ---- dense f64 products of the ZI models on the matrix cores (csrc/dense_mfma.hip) ------------------
 
 @pytest.mark.gpu

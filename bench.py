@@ -55,6 +55,7 @@ WORKLOADS = {
     'c4': (1000000, 30000, 100, 0.10),       # BASELINE.json configs[3] -- the metric's configuration
     'c2': (10000, 2000, 20, 0.10),           # configs[1]
     'c4_eighth': (125000, 30000, 100, 0.10),  # one rank's share of c4 at 8 GPUs
+    'c4_eighth_z05': (125000, 30000, 100, 0.50),  # the same at the reference generator's default z (~53 % zeros)
 }
 
 

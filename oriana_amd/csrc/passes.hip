@@ -120,7 +120,7 @@ struct Stage {
     f4 v[NST];
     f4 t[NTR];
 
-    __device__ __forceinline__ void load(const float *__restrict__ F, int64_t j0, int64_t jmax, int tid) {
+    __device__ __forceinline__ void load_main(const float *__restrict__ F, int64_t j0, int64_t jmax, int tid) {
         // launder the thread index: the per-element index arithmetic must be redone per tile, not
         // hoisted out of the tile loop into a dozen long-lived address registers
         asm volatile("" : "+v"(tid));
@@ -132,6 +132,10 @@ struct Stage {
             // rows past the end are zero-filled: padding slots point at image row 0 and must read finite values
             v[u] = (idx < ROWS * KP4 && j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + c4] : f4{0.f, 0.f, 0.f, 0.f};
         }
+    }
+
+    __device__ __forceinline__ void load_tail(const float *__restrict__ F, int64_t j0, int64_t jmax, int tid) {
+        asm volatile("" : "+v"(tid));
         if (TAILREP > 1) {
             #pragma unroll
             for (int u = 0; u < NTR; ++u) {
@@ -141,6 +145,11 @@ struct Stage {
                                                                : f4{0.f, 0.f, 0.f, 0.f};
             }
         }
+    }
+
+    __device__ __forceinline__ void load(const float *__restrict__ F, int64_t j0, int64_t jmax, int tid) {
+        load_main(F, j0, jmax, tid);
+        load_tail(F, j0, jmax, tid);
     }
 
     template <int STRIDE4>
@@ -462,6 +471,92 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
     #pragma unroll
     for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
+#define ORIANA_COL_STEP(U)                                                                            \
+                {                                                                                     \
+                    float s = qb_f32<U>(svc);                                                         \
+                    int r = (int)qb_u32<U>(rvc);                                                      \
+                    if (NSUB > 1) { if (r / RT != rsub) s = 0.f; r &= (RT - 1); }                      \
+                    const f4 *vrow = lds + r * STRIDE4;                                               \
+                    const f2 ss = {s, s};                                                             \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        const f4 v = ORIANA_LDS_ROW(vrow, choff[tt]);                                 \
+                        acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                 \
+                        acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                 \
+                    }                                                                                 \
+                    if (TAIL) acct = fmaf(s, reinterpret_cast<const float *>(vrow)[toff_lds], acct);  \
+                }
+    if (NSUB == 1) {
+        // One image per tile.  Everything the NEXT tile needs from memory -- its factor rows and the first
+        // CPD iterations of its (s, row index) stream -- is requested CPD iterations before the end of
+        // the current tile, between two branch-free loops (a request inside a loop body would make the
+        // compiler drain the memory counter at every iteration), so that the barrier + image rewrite
+        // between tiles no longer waits for HBM.
+        constexpr int rsub = 0;
+        Stage<KP4, TREP, RT> stg;
+        float svq[CPD]; uint32_t rvq[CPD];
+        int niter = 0;
+        int64_t cbase = 0;
+        auto tile_geo = [&](int64_t rb, int &ni, int64_t &cbs) {
+            const int64_t t = rb * cm.ncb + cb;
+            const uint32_t s0 = cm.cslice[t * 17 + sl], s1 = cm.cslice[t * 17 + sl + 1];
+            ni = __builtin_amdgcn_readfirstlane((int)((s1 - s0) >> 6));
+            cbs = cm.coff[t] + s0 + ent_lane;
+        };
+        auto ring_fill = [&](float (&sv)[CPD], uint32_t (&rv)[CPD], int ni, int64_t cbs) {
+            #pragma unroll
+            for (int d = 0; d < CPD; ++d) {
+                const int id = (d < ni) ? d : (ni > 0 ? ni - 1 : 0);
+                sv[d] = 0.f; rv[d] = 0;
+                if (ni > 0) { sv[d] = s_cs[cbs + (int64_t)id * 64]; rv[d] = cm.ridx[cbs + (int64_t)id * 64]; }
+            }
+        };
+        if (rb0 < rb1) {
+            tile_geo(rb0, niter, cbase);
+            ring_fill(svq, rvq, niter, cbase);
+            stg.load_main(Gm, rb0 * TILE, cm.n, tid);
+        }
+        for (int64_t rb = rb0; rb < rb1; ++rb) {
+            stg.load_tail(Gm, rb * TILE, cm.n, tid);               // the (L2-hot) tail replicas: late, few registers
+            ORIANA_SYNC();
+            stg.template store<STRIDE4>(lds, tid);
+            ORIANA_SYNC();
+            const int n_main = (niter > CPD) ? niter - CPD : 0;
+            for (int it = 0; it < n_main; ++it) {
+                const float svc = svq[0]; const uint32_t rvc = rvq[0];
+                #pragma unroll
+                for (int d = 0; d + 1 < CPD; ++d) { svq[d] = svq[d + 1]; rvq[d] = rvq[d + 1]; }
+                svq[CPD - 1] = s_cs[cbase + (int64_t)(it + CPD) * 64];
+                rvq[CPD - 1] = cm.ridx[cbase + (int64_t)(it + CPD) * 64];
+                ORIANA_COL_STEP(0)
+                ORIANA_COL_STEP(1)
+                ORIANA_COL_STEP(2)
+                ORIANA_COL_STEP(3)
+            }
+            float svn[CPD]; uint32_t rvn[CPD];
+            int niter_n = 0;
+            int64_t cbase_n = 0;
+            if (rb + 1 < rb1) {
+                stg.load_main(Gm, (rb + 1) * TILE, cm.n, tid);
+                tile_geo(rb + 1, niter_n, cbase_n);
+                ring_fill(svn, rvn, niter_n, cbase_n);
+            }
+            for (int it = n_main; it < niter; ++it) {
+                const float svc = svq[0]; const uint32_t rvc = rvq[0];
+                #pragma unroll
+                for (int d = 0; d + 1 < CPD; ++d) { svq[d] = svq[d + 1]; rvq[d] = rvq[d + 1]; }
+                ORIANA_COL_STEP(0)
+                ORIANA_COL_STEP(1)
+                ORIANA_COL_STEP(2)
+                ORIANA_COL_STEP(3)
+            }
+            if (rb + 1 < rb1) {
+                #pragma unroll
+                for (int d = 0; d < CPD; ++d) { svq[d] = svn[d]; rvq[d] = rvn[d]; }
+                niter = niter_n;
+                cbase = cbase_n;
+            }
+        }
+    } else {
     for (int64_t rb = rb0; rb < rb1; ++rb) {
         const int64_t t = rb * cm.ncb + cb;
         const uint32_t s0 = cm.cslice[t * 17 + sl], s1 = cm.cslice[t * 17 + sl + 1];
@@ -481,9 +576,6 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
             ORIANA_SYNC();
             stg.template store<STRIDE4>(lds, tid);
             ORIANA_SYNC();
-            // (An explicit two-image software pipeline of the LDS reads was measured and bought
-            // nothing: the pass is bound by LDS throughput, not latency; the compiler already keeps
-            // 4-6 reads in flight.)
             for (int it = 0; it < niter; ++it) {
                 const float svc = svq[0]; const uint32_t rvc = rvq[0];
                 #pragma unroll
@@ -491,28 +583,15 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
                 const int nx = (it + CPD < niter) ? it + CPD : niter - 1;
                 svq[CPD - 1] = s_cs[cbase + (int64_t)nx * 64];
                 rvq[CPD - 1] = cm.ridx[cbase + (int64_t)nx * 64];
-#define ORIANA_COL_STEP(U)                                                                            \
-                {                                                                                     \
-                    float s = qb_f32<U>(svc);                                                         \
-                    int r = (int)qb_u32<U>(rvc);                                                      \
-                    if (NSUB > 1) { if (r / RT != rsub) s = 0.f; r &= (RT - 1); }                      \
-                    const f4 *vrow = lds + r * STRIDE4;                                               \
-                    const f2 ss = {s, s};                                                             \
-                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
-                        const f4 v = ORIANA_LDS_ROW(vrow, choff[tt]);                                 \
-                        acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                 \
-                        acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                 \
-                    }                                                                                 \
-                    if (TAIL) acct = fmaf(s, reinterpret_cast<const float *>(vrow)[toff_lds], acct);  \
-                }
                 ORIANA_COL_STEP(0)
                 ORIANA_COL_STEP(1)
                 ORIANA_COL_STEP(2)
                 ORIANA_COL_STEP(3)
-#undef ORIANA_COL_STEP
             }
         }
     }
+    }
+#undef ORIANA_COL_STEP
     if (col < cm.m) {
         float *dst = C + col * KP;
         #pragma unroll

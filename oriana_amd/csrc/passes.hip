@@ -86,6 +86,23 @@ constexpr int pick_nsub(int KP) {
     return nsub;
 }
 
+// Chunk (float4 index / G inside a row) that a lane visits at step t.  Default: the per-quad rotation
+// below.  For G = 4, T4 = 6 (K = 100) a rotation cannot keep the four quads of a 16-lane set on distinct
+// 64-byte bank quarters (6 chunks over 4 quarters: two quarters hold two chunks each); the table is a
+// schedule with the minimum number of colliding steps (2 of 6 instead of 3; exhaustive search).
+template <int G, int T4>
+__device__ __forceinline__ int chunk_at(int lane, int rot, int t) {
+#if !defined(ORIANA_ABLATE_ROT0) && !defined(ORIANA_ABLATE_ROTQ) && !defined(ORIANA_ABLATE_ROTQ7) && !defined(ORIANA_ABLATE_NOSCHED)
+    if (G == 4 && T4 == 6) {
+        const int c = (lane >> 2) & 3;
+        int ch = t ^ (c & 1);                                   // classes 1, 3 swap inside the pairs
+        if ((c & 2) && ch >= 2) ch = (ch < 4) ? ch + 2 : ch - 2;   // classes 2, 3 swap the pairs (2,3) <-> (4,5)
+        return ch;
+    }
+#endif
+    return (t + rot) % T4;
+}
+
 template <int G>
 __device__ __forceinline__ int lds_rot(int lane) {
     // ds_read_b128 is serviced in fixed 16-lane sets; quads that are serviced together must start
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
 
     int choff[T4];                              // float4 offset of the chunk visited at step t
     #pragma unroll
-    for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
+    for (int t = 0; t < T4; ++t) choff[t] = chunk_at<G, T4>(lane, rot, t) * G + q;
 
     f4 fu[T4], acc[T4];
     float fut = 0.f, acct = 0.f;                // tail element of this lane
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
     const int toff_lds = TOFF + ((lane >> 2) % TREP) * 4 + q;
     int choff[T4];
     #pragma unroll
-    for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
+    for (int t = 0; t < T4; ++t) choff[t] = chunk_at<G, T4>(lane, rot, t) * G + q;
     f4 acc[T4];
     float acct = 0.f;
     #pragma unroll
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
     const int toff_lds = TOFF + ((lane >> 2) % TREP) * 4 + q;
     int choff[T4];
     #pragma unroll
-    for (int t = 0; t < T4; ++t) choff[t] = ((t + rot) % T4) * G + q;
+    for (int t = 0; t < T4; ++t) choff[t] = chunk_at<G, T4>(lane, rot, t) * G + q;
     f4 acc[T4];
     float acct = 0.f;
     #pragma unroll

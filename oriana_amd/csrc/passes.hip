@@ -25,6 +25,11 @@
 #else
 #define ORIANA_SYNC() __syncthreads()
 #endif
+#if defined(ORIANA_ABLATE_NOSSTORE)
+#define ORIANA_S_STORE(dst, off, v) do { if ((v) == 12345.678f) (dst)[(off)] = (v); } while (0)   /* no scattered s stores */
+#else
+#define ORIANA_S_STORE(dst, off, v) (dst)[(off)] = (v)
+#endif
 #if defined(ORIANA_ABLATE_SAMEROW)
 #define ORIANA_LDS_ROW(base, off) (lds)[(off)]                 /* every group reads image row 0: no bank conflicts */
 #elif defined(ORIANA_ABLATE_HALFLDS)
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                     bad = bad || slow;                                                                \
                     const float sout = slow ? NAN : s;                                                \
                     const uint32_t off = valid ? (bm & 0xFFFFu) : dummy;                              \
-                    sdst[off] = sout;                                                                 \
+                    ORIANA_S_STORE(sdst, off, sout);                                                  \
                     if (HASW) swdst[off] = slow ? NAN : sw;                                           \
                     if (SROW) sbuf = (ql == U) ? sout : sbuf;                                         \
                     /* step fence: one step's K-vector live at a time (keeps the kernel spill-free) */ \

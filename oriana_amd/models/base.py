@@ -52,7 +52,9 @@ class FactorModel:
         gap.py:31), a NumPy array, a torch tensor, or an ``engine.CountTiles`` already resident
         on the device.  With a process group this is the LOCAL row shard.
     k : number of factors.  use_factors : warm-start a1 / b1 from NMF factors (base.py:37-40).
-    init : optional ``(a1, b1)`` arrays (post-clamp initial shapes) -- bypasses NMF / host RNG.
+    init : optional ``(a1, b1)`` arrays (post-clamp initial shapes) -- bypasses NMF / host RNG; or
+        ``'nmf'`` / ``'random'``: starts computed on the device (models/deviceinit.py), for counts that are
+        already resident, sparse or row-sharded (``seed`` keys them by global row).
     device : torch device (default cuda).  process_group : torch.distributed group for row sharding.
     reference_quirks : reproduce zigap.py:94 (``D_hat[i, k]``) -- see SURVEY.md 8(a) policy.
     """
@@ -61,7 +63,7 @@ class FactorModel:
     sparse = False
 
     def __init__(self, cmatrix, k=2, use_factors=True, tau=0.5, init=None, device=None, process_group=None,
-                 reference_quirks=True, n_total=None):
+                 reference_quirks=True, n_total=None, seed=0):
         if not torch.cuda.is_available():
             raise OrianaHipError('oriana_amd needs a ROCm GPU: the CAVI kernels are HIP only (no CPU fallback)')
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
@@ -70,6 +72,7 @@ class FactorModel:
         self.tau = tau
         self.use_factors = use_factors
         self.reference_quirks = reference_quirks
+        self.seed = int(seed)
         self.pg = process_group
         self.world = odist.world_size(process_group)
 
@@ -132,6 +135,21 @@ class FactorModel:
         """a1, b1 before the clamp.  With ``init`` given: exactly those.  Otherwise the reference's
         host-side sequence is replayed (same np.random calls in the same order, then scikit-learn
         NMF) so that ``np.random.seed(s)`` before the constructor gives the reference's start."""
+        if isinstance(init, str):
+            # on-device starts (deviceinit.py): no host copy of X, sharding-invariant
+            from . import deviceinit
+            seed = int(getattr(self, 'seed', 0))
+            row0 = deviceinit.global_row_offset(self.n, self.pg, self.device)
+            if init == 'nmf':
+                W, H = deviceinit.device_nmf(self.counts, self.k, seed=seed, pg=self.pg, row0=row0)
+                if self.use_factors:
+                    return W, H, (W, H)
+                a1, b1 = deviceinit.random_shapes(self.n, self.m, self.k, seed=seed + 1, device=self.device, row0=row0)
+                return a1, b1, (W, H)
+            if init == 'random':
+                a1, b1 = deviceinit.random_shapes(self.n, self.m, self.k, seed=seed, device=self.device, row0=row0)
+                return a1, b1, None
+            raise ValueError("init must be (a1, b1), 'nmf' or 'random'")
         if init is not None:
             a1, b1 = init
             a1 = a1 if isinstance(a1, torch.Tensor) else torch.as_tensor(np.asarray(a1, dtype=np.float64))
@@ -140,9 +158,9 @@ class FactorModel:
                 raise ValueError('init shapes must be (n, k) and (m, k)')
             return a1, b1, None
         if X_host is None:
-            raise ValueError('init=(a1, b1) is required when the count matrix is already on the device')
+            raise ValueError("init=(a1, b1), 'nmf' or 'random' is required when the count matrix is already on the device")
         if self.world > 1:
-            raise ValueError('init=(a1, b1) is required under row sharding (NMF sees the whole matrix)')
+            raise ValueError("init=(a1, b1), 'nmf' or 'random' is required under row sharding (the host NMF sees the whole matrix)")
         from .hostinit import reference_initial_shapes
         a1, b1, nmf = reference_initial_shapes(type(self).__name__, X_host, self.k, self.use_factors)
         return torch.from_numpy(a1), torch.from_numpy(b1), nmf

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden_files, load_golden, state_of, assert_state_close, sparsity_tolerance
+from helpers import golden_files, load_golden, state_of, assert_state_close, sparsity_tolerance, err_colrel
 
 pytestmark = pytest.mark.gpu
 
@@ -217,6 +217,58 @@ def test_metrics_match_oracle(name):
     after = G.state()
     for k in before:
         assert np.array_equal(before[k], after[k], equal_nan=True), k
+
+
+# ---- on-device starts (models/deviceinit.py) -----------------------------------------------------------
+
+def test_device_nmf_properties():
+    """device_nmf stands in for scikit-learn's NMF (an unpinned third-party routine the reference only
+    uses as a starting point, base.py:38-40): non-negative factors, a Frobenius loss that never increases
+    and matches a dense evaluation, recovery of a planted rank-K structure, determinism."""
+    from oriana_amd import engine
+    from oriana_amd.models.deviceinit import device_nmf
+    rng = np.random.default_rng(3)
+    n, m, K = 900, 520, 6
+    Wt = rng.gamma(2.0, 1.0, size=(n, K)) * (rng.random((n, K)) < 0.5)
+    Ht = rng.gamma(2.0, 1.0, size=(m, K)) * (rng.random((m, K)) < 0.5)
+    X = rng.poisson(Wt @ Ht.T).astype(np.float32)
+    ct = engine.CountTiles.from_dense(X, 'cuda')
+    W, H, losses = device_nmf(ct, K, n_iter=60, tol=0.0, seed=5, return_loss=True)
+    W2, H2 = device_nmf(ct, K, n_iter=60, tol=0.0, seed=5)
+    # same seed, same start; the gene-side sums are combined with float atomics, so not bit-identical
+    assert err_colrel(W2.cpu().numpy(), W.cpu().numpy()) < 1e-4 and err_colrel(H2.cpu().numpy(), H.cpu().numpy()) < 1e-4
+    Wh, Hh = W.cpu().numpy(), H.cpu().numpy()
+    assert (Wh >= 0).all() and (Hh >= 0).all() and np.isfinite(Wh).all() and np.isfinite(Hh).all()
+    losses = np.asarray(losses)
+    assert (np.diff(losses) <= 1e-6 * losses[0]).all()                 # never increases (float32 noise only)
+    dense = ((X.astype(np.float64) - Wh @ Hh.T) ** 2).sum()
+    assert abs(losses[-1] / dense - 1.0) < 1e-3
+    # a rank-K Poisson matrix: the fit explains most of the variance around the mean
+    total = ((X - X.mean()) ** 2).sum()
+    assert dense < 0.2 * total
+
+
+def test_models_start_on_device():
+    """init='nmf' / 'random' give a working start without a host copy of X (device tensor, CountMatrix with
+    a SciPy matrix); use_factors selects the NMF factors as shapes like gap.py:49-50, 59-60."""
+    import scipy.sparse as sp
+    import oriana_amd.models as M
+    from oriana_amd.singlecell import CountMatrix
+    rng = np.random.default_rng(4)
+    X = rng.poisson(rng.gamma(0.5, 3.0, size=(520, 300))).astype(np.float32)
+    Xd = torch.from_numpy(X).cuda()
+    g = M.GaP(Xd, k=5, use_factors=True, init='nmf', seed=3)
+    W, H = g.nmf_factors
+    assert np.allclose(g.a1.asarray(), np.maximum(W.cpu().numpy(), 1e-15))
+    g.fit(3)
+    assert np.isfinite(g.a1.asarray()).all() and np.isfinite(g.reconstruction_deviance())
+    z = M.SparseZIGaP(CountMatrix(sp.csr_matrix(X)), k=5, use_factors=False, init='random', seed=3)
+    z2 = M.SparseZIGaP(Xd, k=5, use_factors=False, init='random', seed=3)
+    assert np.array_equal(z.a1.asarray(), z2.a1.asarray())
+    z.fit(2)
+    assert np.isfinite(z.a1.asarray()).all()
+    with pytest.raises(ValueError):
+        M.GaP(Xd, k=5)                                               # no host X and no init recipe
 
 
 def _chunk_sums(gen, n, m):

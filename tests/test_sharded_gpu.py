@@ -93,3 +93,40 @@ def test_two_ranks_match_one(tmp_path, name, fn):
     # the deviances / Frobenius norm are sums over the row shards, all-reduced
     ref_m = np.array([single.reconstruction_deviance(), single.explained_deviance(), single.frobenius_norm()])
     np.testing.assert_allclose(got['metrics'], ref_m, rtol=1e-4)
+
+
+def _nmf_worker(rank, world, port, X, K, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oriana_amd import dist as odist, engine
+        from oriana_amd.models.deviceinit import device_nmf
+        r0, r1 = odist.shard_rows(X.shape[0], rank, world)
+        ct = engine.CountTiles.from_dense(X[r0:r1], torch.device('cuda', 0), reduce_fn=lambda t: odist.all_reduce_sum(t))
+        W, H = device_nmf(ct, K, n_iter=15, tol=0.0, seed=9, pg=dist.group.WORLD)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, W.cpu().numpy())
+        if rank == 0:
+            np.savez(out, W=np.concatenate(gathered), H=H.cpu().numpy())
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
+
+
+def test_device_nmf_sharded_matches_single(tmp_path):
+    """The device NMF start is keyed by global rows: two row shards give the single-process factors
+    (up to the summation order of the all-reduced gene-side sums)."""
+    from oriana_amd import engine
+    from oriana_amd.models.deviceinit import device_nmf
+    rng = np.random.default_rng(8)
+    X = rng.poisson(rng.gamma(0.5, 3.0, size=(9000, 300))).astype(np.float32)     # > 2 blocks of 4096 rows
+    out = str(tmp_path / 'nmf.npz')
+    mp.spawn(_nmf_worker, args=(2, _free_port(), X, 5, out), nprocs=2, join=True)
+    got = np.load(out)
+    W, H = device_nmf(engine.CountTiles.from_dense(X, 'cuda'), 5, n_iter=15, tol=0.0, seed=9)
+    assert err_colrel(got['W'], W.cpu().numpy()) < 1e-4
+    assert err_colrel(got['H'], H.cpu().numpy()) < 1e-4

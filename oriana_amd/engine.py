@@ -3,6 +3,8 @@
 C ABI (include/oriana_hip.h).  torch is used for device memory and streams only."""
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 
@@ -101,10 +103,13 @@ class CountTiles:
              ptr(self.rowrec), ptr(self.ridx), ptr(side), side.stride(0) if side is not None else 0, ptr(side_nz),
              stream_ptr())
 
-    def _build_col_work(self, target_items=2304):
+    def _build_col_work(self, target_items=None):
         """Work list of the column pass: (column block, row-block range) items of about equal
-        COST, longest first.  Genes differ widely in density, so uniform bands would leave the chip
-        waiting for the densest column block.  Cost of a tile = its longest column slice (the
+        COST, launched band of rows by band of rows.  Genes differ widely in density, so uniform bands
+        would leave the chip waiting for the densest column block; and the items that run at the same time
+        should stage the SAME factor rows (at 1M cells the row-side factor is 400 MB, read once per column
+        block: ordering the items by row range keeps the band being worked on in L2 / Infinity Cache --
+        column pass 26.4 -> 25.0 ms at C4 against a longest-first order).  Cost of a tile = its longest column slice (the
         workgroup advances at the pace of its slowest wave) plus a fixed charge for staging the 256
         factor rows (measured on MI355X: ~1.45 us per slice iteration, ~3.2 us per tile)."""
         nt = self.nrb * self.ncb
@@ -115,6 +120,9 @@ class CountTiles:
         nit = ((cs[:, 1:] - cs[:, :-1]) // 64).max(dim=1).values                     # longest slice per tile
         cost = (nit.to(torch.float64) * 1.45 + 3.2).view(self.nrb, self.ncb).cpu().numpy()
         total = float(cost.sum())
+        if target_items is None:
+            # 25-50 tiles per item (each item ends with one atomic flush of its accumulators), at least 9 per CU
+            target_items = min(9216, max(2304, nt // 50))
         target = max(total / target_items, 1e-9)
         items = []
         for cb in range(self.ncb):
@@ -126,7 +134,7 @@ class CountTiles:
             for a, e in zip(edges[:-1], edges[1:]):
                 if e > a:
                     items.append((cum[e] - cum[a], cb, int(a), int(e)))
-        items.sort(key=lambda x: -x[0])
+        items.sort(key=lambda x: (x[2] + x[3], x[1]))          # by row band: concurrent items share factor rows
         arr = np.asarray([[c, a, e] for _, c, a, e in items], dtype=np.int32)
         self.col_work = torch.from_numpy(arr).to(self.device).contiguous()
 

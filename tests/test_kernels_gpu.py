@@ -123,6 +123,23 @@ def test_zq_gap_random(eng, n, m, K, density):
     np.testing.assert_allclose(Zj.sum(1), X.sum(0), rtol=2e-5, atol=1e-3)
 
 
+def test_zq_gap_every_padding_class(eng):
+    """Every kernel configuration the dispatcher can pick (Kp = 16 t or 16 t + 4, lanes per row 4 / 8 / 16,
+    column sub-tiles for Kp > 128) and the K values that pad up to it: K = 1 ... 40 and the class
+    boundaries up to 256, on a two-tile matrix, against the oracle."""
+    rng = np.random.default_rng(99)
+    n, m = 290, 270
+    X = _rand_counts(rng, n, m, 0.2)
+    ks = list(range(1, 41)) + [47, 48, 49, 52, 53, 63, 65, 68, 69, 96, 99, 101, 112, 113, 116, 117, 127, 129, 132,
+                               133, 160, 164, 165, 196, 199, 228, 229, 252, 253, 255]
+    for K in ks:
+        lu = rng.normal(size=(n, K)).astype(np.float32)
+        lv = rng.normal(size=(m, K)).astype(np.float32)
+        Zi, Zj, rZi, rZj, ws = _run_gap(eng, X, lu, lv)
+        assert err_colrel(Zi, rZi) < RTOL, K
+        assert err_colrel(Zj, rZj) < RTOL, K
+
+
 def test_zq_gap_slow_path(eng):
     """Rows / columns outside the range the shifted form covers: exp underflow to denormals,
     den == 0 guard (gap.py:76), huge shifts.  All must land on the reference's float32 answers."""

@@ -53,7 +53,8 @@ class CountTiles:
         self.rowrec = self.ridx = None
         self.nnz = self.rslots = self.cslots = 0
         self.col_perm = None      # int32 [m]: packed column c holds gene col_perm[c] (None = identity)
-        self.row_perm = None
+        self.row_perm = None      # int32 [n]: packed row r holds cell row_perm[r] (None = identity)
+        self.sort_rows = False
         self.side_nz = None
         self.col_work = None
         self._struct = None
@@ -67,13 +68,30 @@ class CountTiles:
         order = torch.argsort(col_nnz.to(self.device), descending=True, stable=True)
         self.col_perm = order.to(torch.int32).contiguous()
 
-    def _permute(self, chunk):
-        if self.col_perm is None:
-            return chunk
-        return chunk.index_select(1, self.col_perm.to(torch.int64)).contiguous()
+    def _permute(self, chunk, r0=None, learn=False):
+        """Apply the internal orderings to a dense row chunk: genes by col_perm; cells, inside the chunk,
+        by decreasing non-zero count (sort_rows, off by default): a 16-row slice advances at the pace of
+        its longest row, so rows of similar depth should share a slice.  On cells whose depth varies 6-fold
+        this cuts the row-side slots by 24 % (slot efficiency 0.51 -> 0.67, tools/row_order_effect.py) but
+        not the time of the row pass, which at that sparsity is dominated by the per-tile costs -- it is a
+        memory option.  The chunk's order is learnt on the counting pass and replayed on the fill pass."""
+        if self.col_perm is not None:
+            chunk = chunk.index_select(1, self.col_perm.to(torch.int64))
+        if self.sort_rows and r0 is not None and chunk.shape[0] > 0:
+            r1 = r0 + chunk.shape[0]
+            if learn:
+                if self.row_perm is None:
+                    self.row_perm = torch.arange(self.n, dtype=torch.int32, device=self.device)
+                rn = (chunk != 0).sum(1)
+                order = torch.argsort(rn, descending=True, stable=True)
+                self.row_perm[r0:r1] = (order + r0).to(torch.int32)
+            else:
+                order = self.row_perm[r0:r1].to(torch.int64) - r0
+            chunk = chunk.index_select(0, order)
+        return chunk.contiguous()
 
     def count_chunk(self, chunk, r0):
-        chunk = self._permute(chunk)
+        chunk = self._permute(chunk, r0, learn=True)
         assert r0 % TILE == 0 and chunk.is_contiguous() and chunk.shape[1] == self.m
         call('oriana_pack_count', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.m, chunk.stride(0),
              r0 // TILE, self.ncb, ptr(self.tile_nnz), ptr(self.tile_rslots), ptr(self.tile_cslots),
@@ -94,9 +112,9 @@ class CountTiles:
         self.ridx = torch.zeros(max(self.cslots, 1), dtype=torch.uint8, device=self.device)
 
     def fill_chunk(self, chunk, r0, side=None, side_nz=None):
-        chunk = self._permute(chunk)
+        chunk = self._permute(chunk, r0)
         if side is not None:
-            side = self._permute(side)
+            side = self._permute(side, r0)
         assert r0 % TILE == 0 and chunk.is_contiguous()
         call('oriana_pack_fill', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.m, chunk.stride(0),
              r0 // TILE, self.ncb, ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
@@ -147,13 +165,15 @@ class CountTiles:
         return self
 
     @classmethod
-    def from_dense(cls, X, device='cuda', chunk_bytes=1 << 30, side=None, sort_cols=True, reduce_fn=None):
+    def from_dense(cls, X, device='cuda', chunk_bytes=1 << 30, side=None, sort_cols=True, reduce_fn=None,
+                   sort_rows=False):
         """Pack a dense (n, m) matrix (NumPy or torch, host or device).  `side`: optional dense
         (n, m) float32 DEVICE matrix gathered at the non-zeros (returned as .side_nz, row-side
         slots).  `reduce_fn`: sums the per-gene counts over row shards (all-reduce) so that every
         rank packs the genes in the same order."""
         n, m = X.shape
         self = cls(n, m, device)
+        self.sort_rows = bool(sort_rows)
         if n == 0 or m == 0:
             self.finish_count()
             return self.finish()
@@ -177,11 +197,12 @@ class CountTiles:
         return self.finish()
 
     @classmethod
-    def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda', sort_cols=True, reduce_fn=None):
+    def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda', sort_cols=True, reduce_fn=None, sort_rows=False):
         """Passes over `chunk_fn(r0, r1) -> dense device tensor` (deterministic generator):
         per-gene counts (when sort_cols), tile counts, fill."""
         assert chunk_rows % TILE == 0
         self = cls(n, m, device)
+        self.sort_rows = bool(sort_rows)
         if sort_cols:
             cn = torch.zeros(m, dtype=torch.int64, device=self.device)
             for r0 in range(0, n, chunk_rows):
@@ -265,6 +286,10 @@ class CountTiles:
                         keep = seg['x'] != 0
                         X[rows[keep], cb * TILE + seg['col'][keep].astype(np.int64)] = seg['x'][keep]
         X = X[:self.n, :self.m]
+        if self.row_perm is not None:
+            out = np.zeros_like(X)
+            out[self.row_perm.cpu().numpy()] = X
+            X = out
         if self.col_perm is not None:
             out = np.zeros_like(X)
             out[:, self.col_perm.cpu().numpy()] = X

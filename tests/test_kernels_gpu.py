@@ -33,15 +33,23 @@ def _rand_counts(rng, n, m, density, maxv=50):
 def test_pack_roundtrip(eng, n, m, density, dtype):
     rng = np.random.default_rng(n * 1000 + m)
     X = _rand_counts(rng, n, m, density).astype(dtype)
-    ct = eng.CountTiles.from_dense(X, 'cuda')
+    ct = eng.CountTiles.from_dense(X, 'cuda', sort_rows=(n % 2 == 1))       # both row orders over the cases
     assert ct.nnz == int((X != 0).sum())
     assert np.array_equal(ct.to_dense(), X.astype(np.float32))
+    if ct.row_perm is not None:
+        # cells are ordered by decreasing depth inside a packing chunk (a permutation of the rows)
+        rp = ct.row_perm.cpu().numpy()
+        assert np.array_equal(np.sort(rp), np.arange(n))
+        depth = (X != 0).sum(1)[rp]
+        assert (np.diff(depth) <= 0).all() or n > 8192
     # column-side structures are consistent with the row-side records
     if ct.nnz:
         h = ct.host_arrays()
         Xp = X.astype(np.float32)
         if ct.col_perm is not None:
             Xp = Xp[:, ct.col_perm.cpu().numpy()]
+        if ct.row_perm is not None:                       # packed row r holds cell row_perm[r]
+            Xp = Xp[ct.row_perm.cpu().numpy()]
         seen_total = 0
         for t in range(ct.nrb * ct.ncb):
             rb, cb = divmod(t, ct.ncb)
@@ -121,6 +129,28 @@ def test_zq_gap_random(eng, n, m, K, density):
     # size-independent property: responsibilities sum to the counts
     np.testing.assert_allclose(Zi.sum(1), X.sum(1), rtol=2e-5, atol=1e-3)
     np.testing.assert_allclose(Zj.sum(1), X.sum(0), rtol=2e-5, atol=1e-3)
+
+
+def test_zq_variants_with_cell_ordering(eng):
+    """The optional internal cell ordering (CountTiles sort_rows) is invisible at the API: the ZI / sparse
+    loop nests on tiles packed with it give the oracle's sums (general D_hat gathered as the side matrix)."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(31)
+    n, m, K = 530, 300, 9
+    X = (_rand_counts(rng, n, m, 0.25) * (rng.random((n, 1)) < 0.7)).astype(np.float32)    # 30 % empty cells
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    D = rng.random((n, m)).astype(np.float32)
+    ps = rng.random((m, K)); St = (ps > 0.4).astype(np.float32); Sh = ps.astype(np.float32)
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    ct = eng.CountTiles.from_dense(c(X), 'cuda', side=c(D), sort_rows=True)
+    assert ct.row_perm is not None
+    ws = eng.ZWorkspace(ct, K)
+    o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+    eng.zq(ws, o[0], o[1], o[2], c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh), w_nz=ct.side_nz)
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_sparse_zigap(r[0], r[1], r[2], lu, lv, St, Sh, D, X)
+    for got, ref in zip(o, r):
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL
 
 
 def test_zq_gap_every_padding_class(eng):

@@ -12,7 +12,7 @@ namespace oriana {
 // blockDim = (KT, RY): thread (tx, ty) handles columns tx, tx + KT, ... of rows ty, ty + RY, ...
 // inside the block's row strip.  Column sums are carried per thread in f64, reduced over ty in
 // LDS and added to the global K-vectors with one f64 atomic per column per block.
-constexpr int GU_ROWS_PER_BLOCK = 512;
+constexpr int GU_ROWS_PER_BLOCK = 512;        // upper bound; rows_per_block() picks fewer for short matrices
 constexpr int GU_MAXCOLS_PER_THREAD = 4;     // K <= 4 * 128
 
 __global__ __launch_bounds__(256) void k_gamma_update(double *__restrict__ a1, double *__restrict__ a2,
@@ -22,12 +22,12 @@ __global__ __launch_bounds__(256) void k_gamma_update(double *__restrict__ a1, d
                                                       const float *__restrict__ Z, const float *__restrict__ zmul,
                                                       const double *__restrict__ rate_vec,
                                                       const double *__restrict__ rate_mat,
-                                                      const float *__restrict__ rmul, int64_t r, int K) {
+                                                      const float *__restrict__ rmul, int64_t r, int K, int rpb) {
     __shared__ double red[2][256];
     const int KT = blockDim.x, RY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * GU_ROWS_PER_BLOCK;
-    const int64_t r1 = (r0 + GU_ROWS_PER_BLOCK < r) ? r0 + GU_ROWS_PER_BLOCK : r;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = (r0 + rpb < r) ? r0 + rpb : r;
     double sE[GU_MAXCOLS_PER_THREAD], sL[GU_MAXCOLS_PER_THREAD];
     #pragma unroll
     for (int c = 0; c < GU_MAXCOLS_PER_THREAD; ++c) { sE[c] = 0.0; sL[c] = 0.0; }
@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void k_gamma_update(double *__restrict__ a1, d
 }
 
 __global__ __launch_bounds__(256) void k_colsum_f64(double *__restrict__ out, const double *__restrict__ A,
-                                                    const float *__restrict__ mul, int64_t r, int K) {
+                                                    const float *__restrict__ mul, int64_t r, int K, int rpb) {
     __shared__ double red[256];
     const int KT = blockDim.x, RY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * GU_ROWS_PER_BLOCK;
-    const int64_t r1 = (r0 + GU_ROWS_PER_BLOCK < r) ? r0 + GU_ROWS_PER_BLOCK : r;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = (r0 + rpb < r) ? r0 + rpb : r;
     for (int c = 0; c < GU_MAXCOLS_PER_THREAD; ++c) {
         const int k = tx + c * KT;
         double s = 0.0;
@@ -147,6 +147,17 @@ static int launch_map(double *y, const double *x, int64_t len, void *stream) {
     return 0;
 }
 
+// Rows per block: enough blocks to fill the chip (>= ~8 per CU) even for a short matrix -- at 512 rows
+// per block the gene side (30,000 rows) ran on 59 of the 256 CUs and one rank's share of the cell side
+// (125,000 rows) on 245, a single 4-wave block each: 0.34 ms per call instead of ~0.1.
+static inline int rows_per_block(int64_t r, int ry) {
+    int64_t rpb = (r + 2047) / 2048;
+    rpb = (rpb + ry - 1) / ry * ry;
+    if (rpb < 4 * ry) rpb = 4 * ry;
+    if (rpb > GU_ROWS_PER_BLOCK) rpb = GU_ROWS_PER_BLOCK;
+    return (int)rpb;
+}
+
 static inline void pick_block(int64_t K, dim3 *block) {
     int kt = 1;
     while (kt < K && kt < 128) kt <<= 1;
@@ -168,9 +179,10 @@ extern "C" int oriana_gamma_update(double *a1, double *a2, double *E, float *Elo
     if (Z && (!prior1 || !prior2 || (!rate_vec && !rate_mat))) return ORIANA_EINVAL;
     dim3 block;
     pick_block(K, &block);
-    const int64_t nblk = (r + GU_ROWS_PER_BLOCK - 1) / GU_ROWS_PER_BLOCK;
+    const int rpb = rows_per_block(r, (int)block.y);
+    const int64_t nblk = (r + rpb - 1) / rpb;
     hipLaunchKernelGGL(k_gamma_update, dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog, colsum_E,
-                       colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K);
+                       colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, rpb);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
@@ -182,8 +194,9 @@ extern "C" int oriana_colsum_f64(double *out, const double *A, const float *mul,
     if (!out || !A) return ORIANA_EINVAL;
     dim3 block;
     pick_block(K, &block);
-    const int64_t nblk = (r + GU_ROWS_PER_BLOCK - 1) / GU_ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(k_colsum_f64, dim3((unsigned)nblk), block, 0, (hipStream_t)stream, out, A, mul, r, (int)K);
+    const int rpb = rows_per_block(r, (int)block.y);
+    const int64_t nblk = (r + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_colsum_f64, dim3((unsigned)nblk), block, 0, (hipStream_t)stream, out, A, mul, r, (int)K, rpb);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -12,7 +12,7 @@ log_U_hat (2 x K float64) -- the U update is row-local, so these partials exist 
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_rows', 'world_size', 'rank', 'all_reduce_sum', 'sum_int']
+__all__ = ['shard_rows', 'world_size', 'rank', 'all_reduce_sum', 'all_reduce_sum_async', 'sum_int']
 
 
 def shard_rows(n_total, rank_, world):
@@ -47,6 +47,15 @@ def all_reduce_sum(t, pg=None):
     if world_size(pg) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
     return t
+
+
+def all_reduce_sum_async(t, pg=None):
+    """Start an in-place sum all-reduce and return a handle with ``wait()`` (None on a single process).
+    On RCCL the collective runs on the communicator's own stream, ordered after the work already queued
+    on the current stream, so kernels launched between this call and ``wait()`` overlap with it."""
+    if world_size(pg) > 1:
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+    return None
 
 
 def sum_int(v, pg=None, device=None):

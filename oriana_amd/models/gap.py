@@ -22,10 +22,13 @@ class GaP(FactorModel):
         """gap.py:82-115 (E-step)."""
         # both Z sums use the PRE-update E[log U], E[log V] (one joint pass, gap.py:89-94)
         engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat)
+        # the only cross-shard quantities of a sweep: the per-gene sums (12 MB at C4) and the U_hat column
+        # sums.  The first does not depend on the U update, so it travels while that update runs.
+        pending = odist.all_reduce_sum_async(self._Zj, self.pg)
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
         self._gamma_side('u', self._Zi, rate_vec=self._sumV[0])
-        # the only cross-shard quantities of a sweep: the per-gene sums and the U_hat column sums
-        odist.all_reduce_sum(self._Zj, self.pg)
         odist.all_reduce_sum(self._sumU, self.pg)
+        if pending is not None:
+            pending.wait()
         # V_q: b1 = beta1 + Z_j ; b2 = beta2 + sum_i U_hat (NEW U_hat)                   gap.py:105-110
         self._gamma_side('v', self._Zj, rate_vec=self._sumU[0])

@@ -167,7 +167,8 @@ def main():
                                    'cells row-sharded over %d GPU(s)' % (args.workload, n_total, m, K, z,
                                                                          100.0 * (1.0 - nnz_total / (float(n_total) * m)), world),
                        'n_cells': n_total, 'n_genes': m, 'K': K, 'nnz': nnz_total, 'rows_per_rank': n,
-                       'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1)},
+                       'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1),
+                       'hbm_gb_rank0': round(torch.cuda.max_memory_allocated() / 1e9, 1)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': recorded_traffic(args.workload, world),
                          'kernel': 'responsibility pass = k_row_pass + k_fixup + k_col_pass (rank 0 shard)',

@@ -23,6 +23,8 @@ namespace oriana {
 constexpr int TILE = ORIANA_TILE;          // 256 x 256 count tiles
 constexpr float DEN_MIN = 1e-10f;          // below this the shifted softmax denominator is not trusted
 constexpr float SHIFT_MAX = 22.0f;         // |row shift| above this -> exact slow path for the row
+constexpr float FILL = 1e-30f;             // factor value of such rows: den <= 256 * 1e-30 < DEN_MIN, but never 0
+constexpr float DEAD_MAX = 40.0f;          // logs of a fully masked row below this: exp(lu + lv) cannot overflow (22 + 40 < 88)
 
 // ---- DPP cross-lane moves (wave64; no LDS traffic) ------------------------------------------
 template <int CTRL>
@@ -46,6 +48,16 @@ __device__ __forceinline__ float group_sum(float v) {
     v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]
     if (G >= 8)  v += dpp_f32<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
     if (G >= 16) v += dpp_f32<0x140>(v);   // row_mirror: lane i <-> 15 - i
+    return v;
+}
+
+// max over aligned groups of G lanes (G = 4, 8, 16)
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    if (G >= 8)  v = fmaxf(v, dpp_f32<0x141>(v));
+    if (G >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
     return v;
 }
 

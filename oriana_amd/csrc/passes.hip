@@ -56,27 +56,43 @@ __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, floa
     const int64_t src = row_index ? (int64_t)row_index[row] : row;
     const float *l = logF + src * K;
     const float *mk = mask ? mask + src * K : nullptr;
-    float mx = -INFINITY;
-    bool bad = false;
+    float mx = -INFINITY, mx_all = -INFINITY;
+    bool bad = false, bad_all = false, any_on = false;
     for (int k = lane; k < K; k += 64) {
         const float v = l[k];
         const bool on = mk ? (mk[k] != 0.0f) : true;
-        if (on) { if (v != v) bad = true; mx = fmaxf(mx, v); }
+        if (v != v) bad_all = true;
+        mx_all = fmaxf(mx_all, v);
+        if (on) { any_on = true; if (v != v) bad = true; mx = fmaxf(mx, v); }
     }
     mx = wave_max(mx);
+    mx_all = wave_max(mx_all);
     bad = __any(bad);
-    // rows the shifted form cannot represent faithfully get an all-zero factor row: every entry
-    // touching them fails the den >= DEN_MIN test and is evaluated by the exact slow path.
-    const bool flagged = bad || !(fabsf(mx) < SHIFT_MAX);
+    bad_all = __any(bad_all);
+    any_on = __any(any_on);
+    // A row whose mask is entirely off (a gene with no active factor, sparse_gap.py:113) multiplies every
+    // exponential by 0: the reference gets den == 0 -> 1 and a contribution of exactly 0 (sparse_gap.py:88-93)
+    // provided no exp(lu + lv) overflows to inf (inf * 0 = NaN).  With its logs below DEAD_MAX and the other
+    // side's shift below SHIFT_MAX that cannot happen: the row is stored as NEGATIVE zeros (a value no other
+    // row can hold), which the row pass of the sparse variants recognises (den == 0 and a -0.0 operand) and
+    // skips without the slow path; everywhere else -0.0 behaves as 0.
+    const bool dead = (mk != nullptr) && !any_on && !bad_all && (mx_all < DEAD_MAX);
+    // Rows the shifted form cannot represent faithfully get a tiny constant instead: every entry touching
+    // them fails the den >= DEN_MIN test (den <= K * FILL) and is evaluated by the exact slow path, and den
+    // stays non-zero, i.e. distinguishable from a dead row.
+    const bool flagged = !dead && (bad || !(fabsf(mx) < SHIFT_MAX));
     for (int k = lane; k < Kp; k += 64) {
-        float out = 0.0f;
-        if (!flagged && k < K) {
-            const float mv = mk ? mk[k] : 1.0f;
-            if (mv != 0.0f) out = (float)exp((double)l[k] - (double)mx) * mv;
+        float out = dead ? -0.0f : 0.0f;                // a dead row is NEGATIVE zero in every (padded) column
+        if (k < K && !dead) {
+            if (flagged) out = FILL;
+            else {
+                const float mv = mk ? mk[k] : 1.0f;
+                if (mv != 0.0f) out = (float)exp((double)l[k] - (double)mx) * mv;
+            }
         }
         F[row * Kp + k] = out;
     }
-    if (mu_out && lane == 0) mu_out[row] = flagged ? NAN : mx;
+    if (mu_out && lane == 0) mu_out[row] = (flagged || dead) ? NAN : mx;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -258,6 +274,18 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
         if (TAIL) fut = FU[row * KP + TOFF + q];
     }
 
+    // Sparse variants (the only ones with masked factor rows): an ordinary row holds exp(0) = 1 at its largest
+    // log; a row that oriana_factor_prep replaced by the FILL constant does not, and its entries must take the
+    // slow path even against a dead (fully masked, -0.0) gene row, whose skip is only certified for
+    // ordinary rows.
+    bool rowfilled = false;
+    if (SROW) {
+        float fm = fut;
+        #pragma unroll
+        for (int t = 0; t < T4; ++t) fm = fmaxf(fmaxf(fmaxf(fu[t].x, fu[t].y), fmaxf(fu[t].z, fu[t].w)), fm);
+        rowfilled = !(group_max<G>(fm) == 1.0f);
+    }
+
     for (int64_t cb = 0; cb < cm.ncb; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
         const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
@@ -323,7 +351,10 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                         acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);             \
                     }                                                                                 \
                     if (TAIL) acct = fmaf(sw, vt, acct);                                              \
-                    const bool slow = valid && !ok;          /* NaN = "evaluate me exactly" */       \
+                    /* fully masked gene (a -0.0 row): exactly zero contribution, no slow path */     \
+                    const bool dead = SROW && !rowfilled && den == 0.f &&                             \
+                                      __float_as_uint(v[0].x) == 0x80000000u;                         \
+                    const bool slow = valid && !ok && !dead; /* NaN = "evaluate me exactly" */       \
                     bad = bad || slow;                                                                \
                     const float sout = slow ? NAN : s;                                                \
                     const uint32_t off = valid ? (bm & 0xFFFFu) : dummy;                              \
@@ -642,7 +673,7 @@ __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const f
     const int64_t o = (row_index ? (int64_t)row_index[row] : row) * K + k;
     float v = F[row * Kp + k] * R[row * Kp + k];
     if (mul) v *= mul[o];
-    Z[o] = accumulate ? Z[o] + v : v;
+    Z[o] = (accumulate ? Z[o] + v : v) + 0.0f;          // (+ 0: a dead factor row is -0.0; the outputs carry +0)
 }
 
 // ------------------------------------------------------------------------------------------

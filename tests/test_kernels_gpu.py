@@ -153,6 +153,50 @@ def test_zq_variants_with_cell_ordering(eng):
         assert err_colrel(got.cpu().numpy(), ref) < RTOL
 
 
+@pytest.mark.parametrize('K', [7, 64, 100])
+def test_zq_sparse_dead_genes(eng, K):
+    """Genes whose mask S_tilde is entirely off (no active factor, sparse_gap.py:113): the reference gets
+    den == 0 -> 1 and exactly zero contributions (sparse_gap.py:88-93).  The kernels skip them without the
+    slow path -- except where exp(lu + lv) could overflow (inf * 0 = NaN in the reference), which stays
+    on the exact path: rows with a huge shift, dead genes with a huge log."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(41 + K)
+    n, m = 300, 520
+    X = _rand_counts(rng, n, m, 0.3).astype(np.float32)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    ps = rng.random((m, K)); St = (ps > 0.3).astype(np.float32); Sh = ps.astype(np.float32)
+    dead = rng.choice(m, size=60, replace=False)
+    St[dead] = 0.0
+    lu[5] += 60.0                        # a row outside the shifted form: exact path, also against dead genes
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    ct = eng.CountTiles.from_dense(c(X), 'cuda')
+    ws = eng.ZWorkspace(ct, K)
+    o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+    eng.zq(ws, o[0], o[1], o[2], c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh))
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_sparse_gap(r[0], r[1], r[2], lu, lv, St, Sh, X)
+    for got, ref in zip(o, r):
+        assert np.isfinite(ref).all()
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL
+    # the dead genes contribute exact (+)zeros; only the shifted row's tiles are flagged
+    zj = o[1].cpu().numpy()
+    assert not zj[dead].any() and not np.signbit(zj[dead]).any()
+    assert 0 < int(ws.tile_flag.sum().item()) <= ct.ncb
+    lu2 = lu.copy(); lu2[5] -= 60.0
+    eng.zq(ws, o[0], o[1], o[2], c(lu2), c(lv), S_tilde=c(St), S_hat=c(Sh))
+    assert int(ws.tile_flag.sum().item()) == 0
+    # A dead gene whose exponentials overflow: the reference forms inf * 0 = NaN there (sparse_gap.py:88).
+    # It is not skipped: its stored entries take the exact path and give the reference's NaN.  (The
+    # reference's dense loop also turns 0 * NaN into NaN for the ZERO counts of such a gene; entries with
+    # x == 0 are never visited here -- DESIGN.md section 2.)
+    lv3 = lv.copy(); lv3[dead[0], 0] = 95.0
+    eng.zq(ws, o[0], o[1], o[2], c(lu2), c(lv3), S_tilde=c(St), S_hat=c(Sh))
+    assert int(ws.tile_flag.sum().item()) > 0
+    zi = o[0].cpu().numpy()
+    hit = X[:, dead[0]] != 0
+    assert hit.any() and np.isnan(zi[hit, 0]).all() and np.isfinite(zi[~hit]).all()
+
+
 def test_zq_gap_every_padding_class(eng):
     """Every kernel configuration the dispatcher can pick (Kp = 16 t or 16 t + 4, lanes per row 4 / 8 / 16,
     column sub-tiles for Kp > 128) and the K values that pad up to it: K = 1 ... 40 and the class

@@ -378,11 +378,18 @@ extern "C" int oriana_dense_times_factor(double *out, const float *D, const doub
         if (trans) rc = launch_dtf<NT_, T_, 1>(out, D, W, P, Q, (int)K, st);                      \
         else rc = launch_dtf<NT_, T_, 0>(out, D, W, P, Q, (int)K, st);                            \
     } while (0)
-    if (nt <= 1) ORIANA_DTF(1, 4);
-    else if (nt <= 2) ORIANA_DTF(2, 4);
-    else if (nt <= 4) ORIANA_DTF(4, 4);
-    else if (nt <= 8) ORIANA_DTF(8, 2);
-    else ORIANA_DTF(16, 1);
+    // NT = ceil(K / 16) tiles of factors, T tiles of p per wave with T * NT <= 16 accumulator tiles
+    switch (nt) {
+        case 1: ORIANA_DTF(1, 4); break;
+        case 2: ORIANA_DTF(2, 4); break;
+        case 3: ORIANA_DTF(3, 4); break;
+        case 4: ORIANA_DTF(4, 4); break;
+        case 5: ORIANA_DTF(5, 3); break;
+        case 6: ORIANA_DTF(6, 2); break;
+        case 7: ORIANA_DTF(7, 2); break;
+        case 8: ORIANA_DTF(8, 2); break;
+        default: ORIANA_DTF(16, 1); break;
+    }
 #undef ORIANA_DTF
     if (rc) return rc;
     ORIANA_LAUNCH_CHECK();

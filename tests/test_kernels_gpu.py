@@ -426,7 +426,8 @@ def test_pack_from_scipy_matches_dense(eng):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,m,K', [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 1024, 100),
-                                   (260, 300, 130), (70, 90, 256), (5000, 3001, 50)])
+                                   (260, 300, 130), (70, 90, 256), (5000, 3001, 50), (300, 260, 40), (260, 300, 70),
+                                   (300, 300, 90), (270, 310, 120)])
 @pytest.mark.parametrize('trans', [0, 1])
 def test_dense_times_factor(n, m, K, trans):
     import torch

@@ -73,6 +73,10 @@ typedef struct {
 
 /* Kp for a given K (0 if K is out of range). */
 int64_t oriana_kpad(int64_t K);
+/* Column tiles (of 256 genes) one work-group of oriana_col_pass covers for this K: the "column block" of a work
+ * item indexes groups of this many adjacent tiles (2 for K = 81..100, where one image of the row block serves two
+ * tiles; 1 otherwise; 0 if K is out of range). */
+int64_t oriana_col_block_tiles(int64_t K);
 /* Library / build identification ("oriana_hip gfx950 <version>"). */
 const char *oriana_version(void);
 
@@ -145,8 +149,9 @@ int oriana_col_pass(const oriana_counts *cm, const float *s_cs,
                     float *C,               /* (m, Kp) accumulated with atomics: zero it first */
                     int64_t K,
                     /* optional work list [nwork][3] = (column block, first row block, end row block):
-                     * one workgroup per item; items should carry similar slot counts (genes differ
-                     * widely in density).  NULL / 0: uniform row bands. */
+                     * one workgroup per item; a column block is oriana_col_block_tiles(K) adjacent column
+                     * tiles; items should carry similar slot counts (genes differ widely in density).
+                     * NULL / 0: uniform row bands. */
                     const int32_t *work, int64_t nwork,
                     void *stream);
 

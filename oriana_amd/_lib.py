@@ -28,6 +28,7 @@ _P = c_void_p
 _I = c_int64
 _SIGS = {
     'oriana_kpad': (c_int64, [_I]),
+    'oriana_col_block_tiles': (c_int64, [_I]),
     'oriana_version': (c_char_p, []),
     'oriana_pack_count': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     'oriana_pack_fill': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

@@ -747,6 +747,466 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
 }
 
 // ------------------------------------------------------------------------------------------
+// K = 81 .. 100 (Kp = 96 or 100): two lanes per row, 32 rows per wave, conflict-free LDS image
+// ------------------------------------------------------------------------------------------
+// What round 1's kernels lose at the headline K = 100 (profiles/r02_sq_pass_c4.json, tools/ubench/core_pass.hip):
+//   * a row of 25 float4 puts chunk groups 4, 5 on the same 64-byte bank quarters as groups 0, 1, so any
+//     schedule of the 6 ds_read_b128 of a step costs 8 LDS cycles per 16-lane service set;
+//   * with four lanes per row every non-FMA instruction of a step (record broadcast, address arithmetic,
+//     reduction, reciprocal, store) serves 16 entries; with two lanes per row it serves 32;
+//   * the column pass restages 256 factor rows per 256 columns.
+// Here a lane pair owns a row / column (48 + 2 floats per lane), a wave works on two 16-row slices of the
+// same packed layout (lanes 0-31: slice 2w, lanes 32-63: slice 2w + 1), and the LDS image stores chunk
+// groups 4, 5 TWICE (float4 16..23 again at 24..31 of the 512-byte row) with the tail float4 in a separate
+// 4-fold array: at every step the 8 pairs of a 16-lane service set (classes 0..7) read 8 different 32-byte
+// bank eighths -- steps 0..7 rotate over pair-chunks 0..7, steps 8..11 read pair-chunks 8..11 from the
+// original (classes 0..3) or from the copy (classes 4..7).  The column pass runs 1024 threads over TWO
+// adjacent column tiles with one image of the row block.
+namespace k100 {
+
+constexpr int T4 = 12;                  // ds_read_b128 per lane and step
+constexpr int ROW4 = 32;                // float4 per LDS image row (512 bytes)
+constexpr int TREP = 4;                 // copies of the tail float4 (64 bytes per image row)
+constexpr int image_bytes(int TAIL) { return TILE * ROW4 * 16 + (TAIL ? TILE * TREP * 16 : 0); }
+
+// ds_read_b128 is serviced in the 16-lane sets {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): pairs
+// {0,1,6,7,10,11,12,13} and {2,3,4,5,8,9,14,15} of a half wave get the classes 0..7 inside their set
+__device__ __forceinline__ int pair_class(int lane) { const int p = (lane >> 1) & 15; return (p >> 2) * 2 + (p & 1); }
+
+// float4 index of the chunk a lane visits at step t: inside a factor row in global memory (24 float4 + tail)
+// and inside the LDS image row
+__device__ __forceinline__ int gchunk(int lane, int t) {
+    const int a = pair_class(lane), q = lane & 1;
+    const int pc = (t < 8) ? ((a + t) & 7) : 8 + ((a + t) & 3);
+    return pc * 2 + q;
+}
+__device__ __forceinline__ int lchunk(int lane, int t) {
+    const int a = pair_class(lane), q = lane & 1;
+    const int pc = (t < 8) ? ((a + t) & 7) : 8 + ((a + t) & 3) + ((a >= 4) ? 4 : 0);
+    return pc * 2 + q;
+}
+
+// broadcast inside a lane pair: lane (U >> 1) of the pair holds the value
+template <int U> __device__ __forceinline__ uint32_t pb_u32(uint32_t v) { return (U >> 1) ? dpp_u32<0xF5>(v) : dpp_u32<0xA0>(v); }
+template <int U> __device__ __forceinline__ float pb_f32(float v) { return (U >> 1) ? dpp_f32<0xF5>(v) : dpp_f32<0xA0>(v); }
+
+// staging of 256 factor rows (global loads before the barrier, LDS stores after it)
+template <int THREADS, int TAIL>
+struct Stage {
+    static constexpr int KP4 = 24 + TAIL;
+    static constexpr int NST = TILE * 24 / THREADS;         // 12 (512 threads) or 6 (1024)
+    f4 v[NST];
+    f4 t;
+    __device__ __forceinline__ void load(const float *__restrict__ F, int64_t j0, int64_t jmax, int tid) {
+        asm volatile("" : "+v"(tid));
+        #pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = tid + u * THREADS;
+            const int jr = idx / 24, c4 = idx - jr * 24;
+            const int64_t j = j0 + jr;
+            v[u] = (j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + c4] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (TAIL) {
+            const int64_t j = j0 + tid;
+            t = (tid < TILE && j < jmax) ? reinterpret_cast<const f4 *>(F)[j * KP4 + 24] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void store(f4 *img, int tid) const {
+        asm volatile("" : "+v"(tid));
+        #pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = tid + u * THREADS;
+            const int jr = idx / 24, c4 = idx - jr * 24;
+            img[jr * ROW4 + c4] = v[u];
+            if (c4 >= 16) img[jr * ROW4 + c4 + 8] = v[u];
+        }
+        if (TAIL && tid < TILE) {
+            f4 *tl = img + TILE * ROW4 + tid * TREP;
+            #pragma unroll
+            for (int r = 0; r < TREP; ++r) tl[r] = t;
+        }
+    }
+};
+
+// ---- row pass ------------------------------------------------------------------------------------
+template <int TAIL, int VAR>
+__global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const float *__restrict__ FU,
+                                                       const float *__restrict__ FV, const float *__restrict__ w_nz,
+                                                       float *__restrict__ R, float *__restrict__ s_cs,
+                                                       float *__restrict__ sw_cs, float *__restrict__ s_rs,
+                                                       int32_t *__restrict__ tile_flag) {
+    constexpr bool SROW = (VAR & 1) != 0, HASW = (VAR & 2) != 0;
+    constexpr int KP = 96 + 4 * TAIL, KP4 = KP / 4;
+    constexpr int PD = 3;                       // record prefetch depth (iterations)
+    extern __shared__ f4 lds[];
+    const float *tails = reinterpret_cast<const float *>(lds + TILE * ROW4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 1, g = (lane >> 1) & 15;
+    const int sl = wave * 2 + (lane >> 5);      // slice of this half wave
+    const int64_t rb = blockIdx.x;
+    const int64_t row = rb * TILE + sl * 16 + g;
+    const int slot_lane = g * 4 + 2 * q;        // this lane's two records inside a 64-slot iteration
+    const int toff = ((lane >> 1) & 3) * 4 + 2 * q;      // float offset inside the 4-fold tail of an image row
+
+    int lidx[T4];
+    #pragma unroll
+    for (int t = 0; t < T4; ++t) lidx[t] = lchunk(lane, t);
+
+    f4 fu[T4], acc[T4];
+    f2 fut = {0.f, 0.f}, acct = {0.f, 0.f};
+    #pragma unroll
+    for (int t = 0; t < T4; ++t) { acc[t] = f4{0.f, 0.f, 0.f, 0.f}; fu[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+    if (row < cm.n) {
+        #pragma unroll
+        for (int t = 0; t < T4; ++t) fu[t] = reinterpret_cast<const f4 *>(FU)[row * KP4 + gchunk(lane, t)];
+        if (TAIL) fut = *reinterpret_cast<const f2 *>(FU + row * KP + 96 + 2 * q);
+    }
+    bool rowfilled = false;                     // see k_row_pass: rows replaced by the FILL constant (sparse variants)
+    if (SROW) {
+        float fm = fmaxf(fut.x, fut.y);
+        #pragma unroll
+        for (int t = 0; t < T4; ++t) fm = fmaxf(fmaxf(fmaxf(fu[t].x, fu[t].y), fmaxf(fu[t].z, fu[t].w)), fm);
+        fm = fmaxf(fm, dpp_f32<0xB1>(fm));
+        rowfilled = !(fm == 1.0f);
+    }
+
+    for (int64_t cb = 0; cb < cm.ncb; ++cb) {
+        const int64_t t = rb * cm.ncb + cb;
+        const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
+        const int nit = (int)((s1 - s0) >> 6);                    // iterations of this half wave's slice
+        const int niter = max(__builtin_amdgcn_readlane(nit, 0), __builtin_amdgcn_readlane(nit, 32));
+        const int64_t rbase = cm.roff[t] + s0 + slot_lane;
+        const uint4 *recp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned long long *>(cm.rowrec) + rbase);
+        float *sdst = s_cs + cm.coff[t];
+        float *swdst = HASW ? sw_cs + cm.coff[t] : nullptr;
+        const uint32_t dummy = cm.cslice[t * 17 + 16] + lane;
+        bool bad = false;
+        // record prefetch ring (two 8-byte records per lane and iteration), clamped to the slice's own length
+        uint4 rawq[PD];
+        f2 wq[PD];
+        #pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int id = (d < nit) ? d : nit - 1;
+            rawq[d] = uint4{0u, 0u, 0u, 0u}; wq[d] = f2{1.f, 1.f};
+            if (nit > 0) { rawq[d] = recp[(int64_t)id * 32]; if (HASW) wq[d] = *reinterpret_cast<const f2 *>(w_nz + rbase + (int64_t)id * 64); }
+        }
+        Stage<512, TAIL> stg;
+        stg.load(FV, cb * TILE, cm.m, tid);
+        ORIANA_SYNC();
+        stg.store(lds, tid);
+        ORIANA_SYNC();
+        for (int it = 0; it < niter; ++it) {
+            const bool live = it < nit;
+            uint4 cur = rawq[0];
+            const f2 wcur = wq[0];
+            #pragma unroll
+            for (int d = 0; d + 1 < PD; ++d) { rawq[d] = rawq[d + 1]; wq[d] = wq[d + 1]; }
+            const int nx = (it + PD < nit) ? it + PD : nit - 1;
+            if (nit > 0) { rawq[PD - 1] = recp[(int64_t)nx * 32]; if (HASW) wq[PD - 1] = *reinterpret_cast<const f2 *>(w_nz + rbase + (int64_t)nx * 64); }
+            if (!live) { cur.x = 0u; cur.z = 0u; }               // past the end of the shorter slice: padding
+            f2 sbuf = {0.f, 0.f};
+#define ORIANA_ROW_STEP2(U)                                                                           \
+            {                                                                                         \
+                const uint32_t bm = pb_u32<U>((U & 1) ? cur.w : cur.y);                               \
+                const float x = __uint_as_float(pb_u32<U>((U & 1) ? cur.z : cur.x));                  \
+                const int col = (int)((bm >> 16) & 0xFFu);                                            \
+                const bool valid = (x != 0.f);                                                        \
+                const f4 *vrow = lds + col * ROW4;                                                    \
+                f4 v[T4];                                                                             \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) v[tt] = vrow[lidx[tt]];             \
+                f2 vt = {0.f, 0.f};                                                                   \
+                if (TAIL) vt = *reinterpret_cast<const f2 *>(tails + col * (TREP * 4) + toff);        \
+                f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};                                                \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
+                    d01 = __builtin_elementwise_fma(fu[tt].xy, v[tt].xy, d01);                        \
+                    d23 = __builtin_elementwise_fma(fu[tt].zw, v[tt].zw, d23);                        \
+                }                                                                                     \
+                if (TAIL) d01 = __builtin_elementwise_fma(fut, vt, d01);                              \
+                const f2 dd = d01 + d23;                                                              \
+                float den = dd.x + dd.y;                                                              \
+                den += dpp_f32<0xB1>(den);                                                            \
+                const bool ok = den >= DEN_MIN;          /* false for 0, tiny and NaN */              \
+                const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;                 \
+                const float sw = HASW ? s * pb_f32<U>((U & 1) ? wcur.y : wcur.x) : s;                 \
+                const f2 ss = {sw, sw};                                                               \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
+                    acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);                 \
+                    acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);                 \
+                }                                                                                     \
+                if (TAIL) acct = __builtin_elementwise_fma(ss, vt, acct);                             \
+                const bool dead = SROW && !rowfilled && den == 0.f &&                                 \
+                                  __float_as_uint(v[0].x) == 0x80000000u;                             \
+                const bool slow = valid && !ok && !dead;                                              \
+                bad = bad || slow;                                                                    \
+                const float sout = slow ? NAN : s;                                                    \
+                const uint32_t off = valid ? (bm & 0xFFFFu) : dummy;                                  \
+                ORIANA_S_STORE(sdst, off, sout);                                                      \
+                if (HASW) swdst[off] = slow ? NAN : sw;                                               \
+                if (SROW && (U >> 1) == q) { if (U & 1) sbuf.y = sout; else sbuf.x = sout; }          \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(acc[tt]));  \
+                asm volatile("" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w));                \
+            }
+            ORIANA_ROW_STEP2(0)
+            ORIANA_ROW_STEP2(1)
+            ORIANA_ROW_STEP2(2)
+            ORIANA_ROW_STEP2(3)
+#undef ORIANA_ROW_STEP2
+            if (SROW && live) *reinterpret_cast<f2 *>(s_rs + rbase + (int64_t)it * 64) = sbuf;
+        }
+        if (__any(bad) && lane == 0) tile_flag[t] = 1;
+    }
+    if (row < cm.n) {
+        #pragma unroll
+        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + gchunk(lane, t)] = acc[t];
+        if (TAIL) *reinterpret_cast<f2 *>(R + row * KP + 96 + 2 * q) = acct;
+    }
+}
+
+// ---- column pass: two adjacent column tiles per work-group, one image of the row block -------------
+// Four lanes per column as in k_col_pass (a 1024-thread group leaves 128 registers per lane: two lanes per column
+// would keep only two of the twelve reads of a step in flight), 16 waves = the 16 column slices of a tile; every
+// wave walks its slice of the FIRST tile of the pair and then its slice of the SECOND one against the same image
+// (two accumulator sets): half the staging, and the tile barrier waits for the sum of two slices.
+__device__ __forceinline__ int quad_class(int lane) { const int Q = lane >> 2; return ((Q & 1) << 1) | ((Q >> 1) & 1); }
+__device__ __forceinline__ int gchunk4(int lane, int t) {
+    const int a = quad_class(lane), q = lane & 3;
+    const int cg = (t < 4) ? ((a + t) & 3) : 4 + ((a & 1) ^ (t & 1));
+    return cg * 4 + q;
+}
+__device__ __forceinline__ int lchunk4(int lane, int t) {
+    const int a = quad_class(lane), q = lane & 3;
+    const int cg = (t < 4) ? ((a + t) & 3) : 4 + ((a & 1) ^ (t & 1)) + 2 * (a >> 1);
+    return cg * 4 + q;
+}
+
+template <int TAIL>
+__global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const float *__restrict__ s_cs,
+                                                        const float *__restrict__ Gm, float *__restrict__ C,
+                                                        const int32_t *__restrict__ work, int64_t rb_per_band) {
+    constexpr int KP = 96 + 4 * TAIL;
+    constexpr int CPD = 3;
+    extern __shared__ f4 lds[];
+    const float *tails = reinterpret_cast<const float *>(lds + TILE * ROW4);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sl = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = column slice of both tiles
+    const int q = lane & 3;
+    int64_t c2, rb0, rb1;
+    if (work) {
+        c2 = work[(int64_t)blockIdx.x * 3 + 0]; rb0 = work[(int64_t)blockIdx.x * 3 + 1]; rb1 = work[(int64_t)blockIdx.x * 3 + 2];
+    } else {
+        c2 = blockIdx.x;
+        rb0 = (int64_t)blockIdx.y * rb_per_band;
+        rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
+    }
+    const int64_t cbA = c2 * 2, cbB = c2 * 2 + 1;
+    const bool hasB = cbB < cm.ncb;
+    const int toff = ((lane >> 2) & 3) * 4 + q;
+    int lidx[6];
+    #pragma unroll
+    for (int t = 0; t < 6; ++t) lidx[t] = lchunk4(lane, t);
+    f4 accA[6], accB[6];
+    float actA = 0.f, actB = 0.f;
+    #pragma unroll
+    for (int t = 0; t < 6; ++t) { accA[t] = f4{0.f, 0.f, 0.f, 0.f}; accB[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+
+    // stream of one slice: (s, row index) per slot; the loads are unconditional -- an index past the slice's end is
+    // clamped, and with an empty slice it reads (and discards) slots that still lie inside the tile's region, which
+    // ends with 64 dummy slots
+    struct Stream { const float *sb; const uint8_t *rb; int nit; float sv[CPD]; uint32_t rv[CPD]; };
+    auto open_stream = [&](Stream &st, int64_t t, bool present) {
+        // everything but the lane index is wave-uniform: the bases stay in scalar registers
+        const uint32_t s0 = cm.cslice[t * 17 + sl];
+        const uint32_t s1 = present ? cm.cslice[t * 17 + sl + 1] : s0;
+        st.nit = (int)((s1 - s0) >> 6);
+        const int64_t base = cm.coff[t] + s0;
+        st.sb = s_cs + base;
+        st.rb = cm.ridx + base;
+        const int last = (st.nit > 0) ? st.nit - 1 : 0;
+        #pragma unroll
+        for (int d = 0; d < CPD; ++d) {
+            const int id = (d < last) ? d : last;
+            st.sv[d] = st.sb[id * 64 + lane];
+            st.rv[d] = st.rb[id * 64 + lane];
+        }
+    };
+#define ORIANA_COL_STEP4(ACC, ACT, U)                                                                 \
+                {                                                                                     \
+                    const float s = qb_f32<U>(svc);                                                   \
+                    const int r = (int)qb_u32<U>(rvc);                                                \
+                    const f4 *vrow = lds + r * ROW4;                                                  \
+                    const f2 ss = {s, s};                                                             \
+                    _Pragma("unroll") for (int tt = 0; tt < 6; ++tt) {                                \
+                        const f4 v = vrow[lidx[tt]];                                                  \
+                        ACC[tt].xy = __builtin_elementwise_fma(ss, v.xy, ACC[tt].xy);                 \
+                        ACC[tt].zw = __builtin_elementwise_fma(ss, v.zw, ACC[tt].zw);                 \
+                    }                                                                                 \
+                    if (TAIL) ACT = fmaf(s, tails[r * (TREP * 4) + toff], ACT);                       \
+                    /* step fence: one step's K-vector live at a time (both accumulator sets stay in registers) */ \
+                    _Pragma("unroll") for (int tt = 0; tt < 6; ++tt) asm volatile("" : "+v"(ACC[tt]));  \
+                    asm volatile("" : "+v"(svc), "+v"(rvc));                                          \
+                }
+#define ORIANA_COL_RUN4(ST, ACC, ACT)                                                                 \
+            {                                                                                         \
+                const int last = (ST.nit > 0) ? ST.nit - 1 : 0;                                       \
+                for (int it = 0; it < ST.nit; ++it) {                                                 \
+                    float svc = ST.sv[0]; uint32_t rvc = ST.rv[0];                                    \
+                    _Pragma("unroll") for (int d = 0; d + 1 < CPD; ++d) { ST.sv[d] = ST.sv[d + 1]; ST.rv[d] = ST.rv[d + 1]; } \
+                    const int nx = (it + CPD < last) ? it + CPD : last;                               \
+                    ST.sv[CPD - 1] = ST.sb[nx * 64 + lane];                                           \
+                    ST.rv[CPD - 1] = ST.rb[nx * 64 + lane];                                           \
+                    ORIANA_COL_STEP4(ACC, ACT, 0)                                                     \
+                    ORIANA_COL_STEP4(ACC, ACT, 1)                                                     \
+                    ORIANA_COL_STEP4(ACC, ACT, 2)                                                     \
+                    ORIANA_COL_STEP4(ACC, ACT, 3)                                                     \
+                }                                                                                     \
+            }
+    Stream stA, stB, stN;
+    if (rb0 < rb1) open_stream(stA, rb0 * cm.ncb + cbA, true);
+    for (int64_t rb = rb0; rb < rb1; ++rb) {
+        open_stream(stB, rb * cm.ncb + (hasB ? cbB : cbA), hasB);      // in flight during the first tile's loop
+        Stage<1024, TAIL> stg;
+        stg.load(Gm, rb * TILE, cm.n, tid);
+        ORIANA_SYNC();
+        stg.store(lds, tid);
+        ORIANA_SYNC();
+        ORIANA_COL_RUN4(stA, accA, actA)
+        // the next row block's first stream is requested before the second tile's loop: its (HBM) latency is
+        // hidden behind that loop instead of being paid between two images
+        if (rb + 1 < rb1) open_stream(stN, (rb + 1) * cm.ncb + cbA, true);
+        ORIANA_COL_RUN4(stB, accB, actB)
+        stA = stN;
+    }
+#undef ORIANA_COL_RUN4
+#undef ORIANA_COL_STEP4
+    const int cl = sl * 16 + (lane >> 2);
+    #pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t col = (h ? cbB : cbA) * TILE + cl;
+        if ((h == 0 || hasB) && col < cm.m) {
+            float *dst = C + col * KP;
+            #pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const f4 a4 = h ? accB[t] : accA[t];
+                float *d = dst + gchunk4(lane, t) * 4;
+                if (a4.x != 0.f) atomicAdd(d + 0, a4.x);
+                if (a4.y != 0.f) atomicAdd(d + 1, a4.y);
+                if (a4.z != 0.f) atomicAdd(d + 2, a4.z);
+                if (a4.w != 0.f) atomicAdd(d + 3, a4.w);
+            }
+            const float at = h ? actB : actA;
+            if (TAIL && at != 0.f) atomicAdd(dst + 96 + q, at);
+        }
+    }
+}
+
+// ---- column pass, variant: two lanes per column, 16 waves x 32 columns = two tiles side by side ------
+template <int TAIL>
+__global__ __launch_bounds__(1024) void k_col_pass_k100_g2(oriana_counts cm, const float *__restrict__ s_cs,
+                                                           const float *__restrict__ Gm, float *__restrict__ C,
+                                                           const int32_t *__restrict__ work, int64_t rb_per_band) {
+    constexpr int KP = 96 + 4 * TAIL;
+    constexpr int CPD = 2;
+    extern __shared__ f4 lds[];
+    const float *tails = reinterpret_cast<const float *>(lds + TILE * ROW4);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 1, g = (lane >> 1) & 15;
+    int64_t c2, rb0, rb1;
+    if (work) {
+        c2 = work[(int64_t)blockIdx.x * 3 + 0]; rb0 = work[(int64_t)blockIdx.x * 3 + 1]; rb1 = work[(int64_t)blockIdx.x * 3 + 2];
+    } else {
+        c2 = blockIdx.x;
+        rb0 = (int64_t)blockIdx.y * rb_per_band;
+        rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
+    }
+    const int64_t cb = c2 * 2 + (wave >> 3);                       // waves 0-7: first tile of the pair, 8-15: second
+    const bool has = cb < cm.ncb;                                  // (wave-uniform)
+    const int slA = (wave & 7) * 2;                                // lanes 0-31: slice slA, lanes 32-63: slA + 1
+    const int hi = lane >> 5;
+    const int64_t col = cb * TILE + (slA + hi) * 16 + g;
+    const int lane_off = g * 4 + 2 * q;                            // this lane's two entries inside a 64-slot iteration
+    const int toff = ((lane >> 1) & 3) * 4 + 2 * q;
+    int lidx[T4];
+    #pragma unroll
+    for (int t = 0; t < T4; ++t) lidx[t] = lchunk(lane, t);
+    f4 acc[T4];
+    f2 acct = {0.f, 0.f};
+    #pragma unroll
+    for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t rb = rb0; rb < rb1; ++rb) {
+        const int64_t t = rb * cm.ncb + (has ? cb : 0);
+        // the three slice offsets of this wave are scalars; each half wave selects its own
+        const uint32_t sA = cm.cslice[t * 17 + slA], sM = cm.cslice[t * 17 + slA + 1], sE = cm.cslice[t * 17 + slA + 2];
+        const int nitA = has ? (int)((sM - sA) >> 6) : 0, nitB = has ? (int)((sE - sM) >> 6) : 0;
+        const int niter = max(nitA, nitB);
+        const int nit = hi ? nitB : nitA;
+        const float *sb = s_cs + cm.coff[t];                       // scalar base; per-lane 32-bit offsets
+        const uint8_t *rbp = cm.ridx + cm.coff[t];
+        const uint32_t o0 = (hi ? sM : sA) + (uint32_t)lane_off;
+        const int last = (nit > 0) ? nit - 1 : 0;
+        f2 svq[CPD]; uint32_t rvq[CPD];
+        #pragma unroll
+        for (int d = 0; d < CPD; ++d) {
+            const uint32_t o = o0 + (uint32_t)((d < last) ? d : last) * 64u;
+            svq[d] = *reinterpret_cast<const f2 *>(sb + o);
+            rvq[d] = *reinterpret_cast<const uint16_t *>(rbp + o);
+        }
+        Stage<1024, TAIL> stg;
+        stg.load(Gm, rb * TILE, cm.n, tid);
+        ORIANA_SYNC();
+        stg.store(lds, tid);
+        ORIANA_SYNC();
+        for (int it = 0; it < niter; ++it) {
+            f2 svc = svq[0]; uint32_t rvc = rvq[0];
+            #pragma unroll
+            for (int d = 0; d + 1 < CPD; ++d) { svq[d] = svq[d + 1]; rvq[d] = rvq[d + 1]; }
+            const uint32_t o = o0 + (uint32_t)((it + CPD < last) ? it + CPD : last) * 64u;
+            svq[CPD - 1] = *reinterpret_cast<const f2 *>(sb + o);
+            rvq[CPD - 1] = *reinterpret_cast<const uint16_t *>(rbp + o);
+            if (it >= nit) svc = f2{0.f, 0.f};                    // the shorter slice of the wave is done
+#define ORIANA_COL_STEP2(U)                                                                           \
+            {                                                                                         \
+                const float s = pb_f32<U>((U & 1) ? svc.y : svc.x);                                   \
+                const int r = (int)((pb_u32<U>(rvc) >> ((U & 1) * 8)) & 0xFFu);                       \
+                const f4 *vrow = lds + r * ROW4;                                                      \
+                const f2 ss = {s, s};                                                                 \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
+                    const f4 v = vrow[lidx[tt]];                                                      \
+                    acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                     \
+                    acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                     \
+                }                                                                                     \
+                if (TAIL) acct = __builtin_elementwise_fma(ss, *reinterpret_cast<const f2 *>(tails + r * (TREP * 4) + toff), acct); \
+                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(acc[tt]));  \
+                asm volatile("" : "+v"(svc.x), "+v"(svc.y), "+v"(rvc));                               \
+            }
+            ORIANA_COL_STEP2(0)
+            ORIANA_COL_STEP2(1)
+            ORIANA_COL_STEP2(2)
+            ORIANA_COL_STEP2(3)
+#undef ORIANA_COL_STEP2
+        }
+    }
+    if (has && col < cm.m) {
+        float *dst = C + col * KP;
+        #pragma unroll
+        for (int t = 0; t < T4; ++t) {
+            float *d = dst + gchunk(lane, t) * 4;
+            if (acc[t].x != 0.f) atomicAdd(d + 0, acc[t].x);
+            if (acc[t].y != 0.f) atomicAdd(d + 1, acc[t].y);
+            if (acc[t].z != 0.f) atomicAdd(d + 2, acc[t].z);
+            if (acc[t].w != 0.f) atomicAdd(d + 3, acc[t].w);
+        }
+        if (TAIL) {
+            if (acct.x != 0.f) atomicAdd(dst + 96 + 2 * q, acct.x);
+            if (acct.y != 0.f) atomicAdd(dst + 96 + 2 * q + 1, acct.y);
+        }
+    }
+}
+
+}  // namespace k100
+
+// ------------------------------------------------------------------------------------------
 // dispatch on K:  Kp = 4 * G * T4
 // ------------------------------------------------------------------------------------------
 struct KCfg { int G, T4, TAIL; };
@@ -789,6 +1249,13 @@ static inline bool pick_cfg(int64_t K, KCfg *c) {
         else return ORIANA_EKRANGE;                                                     \
     } while (0)
 
+// The K = 81..100 kernels (namespace k100) replace the generic ones for Kp = 96 / 100 unless the environment
+// says ORIANA_PASS_IMPL=r1 (A/B measurements, tools/perf1.py).
+static bool use_k100(int G, int T4) {
+    static const bool off = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && e[1] == '1'; }();
+    return !off && G == 4 && T4 == 6;
+}
+
 template <typename KernelT>
 static int set_lds(KernelT kern, size_t bytes) {
     if (bytes > 64 * 1024) {
@@ -807,10 +1274,25 @@ static inline size_t lds_bytes(int G, int T4, int TAIL) {
 template <int G, int T4, int TAIL>
 static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
                            float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s) {
-    const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
-    const size_t lb = lds_bytes(G, T4, TAIL);
     const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
+    if (use_k100(G, T4)) {
+        constexpr int TL = (G == 4 && T4 == 6) ? TAIL : 0;
+        const size_t lb2 = k100::image_bytes(TL);
+#define ORIANA_RP2(V)                                                                                 \
+        rc = set_lds(k100::k_row_pass_k100<TL, V>, lb2);                                              \
+        if (rc) return rc;                                                                            \
+        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)cm->nrb), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
+        if (var == 0) { ORIANA_RP2(0); }
+        else if (var == 1) { ORIANA_RP2(1); }
+        else if (var == 2) { ORIANA_RP2(2); }
+        else { ORIANA_RP2(3); }
+#undef ORIANA_RP2
+        ORIANA_LAUNCH_CHECK();
+        return 0;
+    }
+    const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
+    const size_t lb = lds_bytes(G, T4, TAIL);
 #define ORIANA_RP(V)                                                                                  \
     rc = set_lds(k_row_pass<G, T4, TAIL, V>, lb);                                                           \
     if (rc) return rc;                                                                                \
@@ -845,6 +1327,32 @@ template <int G, int T4, int TAIL>
 static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C,
                            const int32_t *work, int64_t nwork, hipStream_t s) {
     constexpr int SPLIT = WaveGeo<G>::SPLIT;
+    if (use_k100(G, T4)) {
+        // work items / grid.x index PAIRS of column tiles (oriana_col_block_tiles = 2)
+        constexpr int TL = (G == 4 && T4 == 6) ? TAIL : 0;
+        const size_t lb2 = k100::image_bytes(TL);
+        static const bool g2 = [] { const char *e = getenv("ORIANA_COL_IMPL"); return e && e[0] == 'g' && e[1] == '2'; }();
+        auto kern = g2 ? k100::k_col_pass_k100_g2<TL> : k100::k_col_pass_k100<TL>;
+        int rc2 = set_lds(kern, lb2);
+        if (rc2) return rc2;
+        if (work) {
+            if (nwork <= 0) return 0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(1024), lb2, s, *cm, s_cs, Gm, C, work, (int64_t)0);
+        } else {
+            const int64_t ncp = (cm->ncb + 1) / 2;
+            int64_t nb = (1024 + ncp - 1) / ncp;
+            const int64_t maxb = (cm->nrb + 7) / 8;
+            if (nb > maxb) nb = maxb;
+            if (nb < 1) nb = 1;
+            if (nb > 65535) nb = 65535;
+            const int64_t per = (cm->nrb + nb - 1) / nb;
+            nb = (cm->nrb + per - 1) / per;
+            hipLaunchKernelGGL(kern, dim3((unsigned)ncp, (unsigned)nb), dim3(1024), lb2, s, *cm, s_cs, Gm, C,
+                               (const int32_t *)nullptr, per);
+        }
+        ORIANA_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lbw = lds_bytes(G, T4, TAIL);
     if (work) {
         if (nwork <= 0) return 0;
@@ -882,7 +1390,13 @@ extern "C" int64_t oriana_kpad(int64_t K) {
     return 4 * c.G * c.T4 + c.G * c.TAIL;
 }
 
-extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.2"; }
+extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.3"; }
+
+extern "C" int64_t oriana_col_block_tiles(int64_t K) {
+    KCfg c;
+    if (!pick_cfg(K, &c)) return 0;
+    return use_k100(c.G, c.T4) ? 2 : 1;
+}
 
 static bool counts_ok(const oriana_counts *cm) {
     if (!cm || cm->n < 0 || cm->m < 0) return false;

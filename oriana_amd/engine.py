@@ -56,7 +56,7 @@ class CountTiles:
         self.row_perm = None      # int32 [n]: packed row r holds cell row_perm[r] (None = identity)
         self.sort_rows = False
         self.side_nz = None
-        self.col_work = None
+        self._col_work = {}
         self._struct = None
 
     # ---- building -------------------------------------------------------------------------
@@ -121,9 +121,11 @@ class CountTiles:
              ptr(self.rowrec), ptr(self.ridx), ptr(side), side.stride(0) if side is not None else 0, ptr(side_nz),
              stream_ptr())
 
-    def _build_col_work(self, target_items=None):
+    def _build_col_work(self, target_items=None, width=1):
         """Work list of the column pass: (column block, row-block range) items of about equal
-        COST, launched band of rows by band of rows.  Genes differ widely in density, so uniform bands
+        COST, launched band of rows by band of rows.  A column block is `width` adjacent column tiles
+        (oriana_col_block_tiles(K): the K = 81..100 kernel serves two tiles with one image of the row block).
+        Genes differ widely in density, so uniform bands
         would leave the chip waiting for the densest column block; and the items that run at the same time
         should stage the SAME factor rows (at 1M cells the row-side factor is 400 MB, read once per column
         block: ordering the items by row range keeps the band being worked on in L2 / Infinity Cache --
@@ -132,18 +134,22 @@ class CountTiles:
         factor rows (measured on MI355X: ~1.45 us per slice iteration, ~3.2 us per tile)."""
         nt = self.nrb * self.ncb
         if nt == 0 or self.cslots == 0:
-            self.col_work = None
-            return
+            return None
         cs = self.cslice[:nt * 17].view(nt, 17).to(torch.int64)
         nit = ((cs[:, 1:] - cs[:, :-1]) // 64).max(dim=1).values                     # longest slice per tile
-        cost = (nit.to(torch.float64) * 1.45 + 3.2).view(self.nrb, self.ncb).cpu().numpy()
+        nit = nit.view(self.nrb, self.ncb).cpu().numpy().astype(np.float64)
+        nblk = (self.ncb + width - 1) // width
+        if width > 1:                                                                  # the block advances at the pace of its slowest tile
+            pad = np.zeros((self.nrb, nblk * width - self.ncb))
+            nit = np.concatenate([nit, pad], axis=1).reshape(self.nrb, nblk, width).max(axis=2)
+        cost = nit * 1.45 + 3.2
         total = float(cost.sum())
         if target_items is None:
             # 25-50 tiles per item (each item ends with one atomic flush of its accumulators), at least 9 per CU
-            target_items = min(9216, max(2304, nt // 50))
+            target_items = min(9216, max(2304, nt // (50 * width)))
         target = max(total / target_items, 1e-9)
         items = []
-        for cb in range(self.ncb):
+        for cb in range(nblk):
             cum = np.concatenate([[0.0], np.cumsum(cost[:, cb])])
             nb = int(min(self.nrb, max(1, round(cum[-1] / target))))
             # cut the column block at equal-cost points
@@ -154,10 +160,17 @@ class CountTiles:
                     items.append((cum[e] - cum[a], cb, int(a), int(e)))
         items.sort(key=lambda x: (x[2] + x[3], x[1]))          # by row band: concurrent items share factor rows
         arr = np.asarray([[c, a, e] for _, c, a, e in items], dtype=np.int32)
-        self.col_work = torch.from_numpy(arr).to(self.device).contiguous()
+        return torch.from_numpy(arr).to(self.device).contiguous()
+
+    def col_work_for(self, K):
+        """The work list matching the column tiles per work-group of the kernel that serves this K (cached)."""
+        width = int(_lib.load().oriana_col_block_tiles(int(K))) or 1
+        if width not in self._col_work:
+            self._col_work[width] = self._build_col_work(width=width)
+        return self._col_work[width]
 
     def finish(self):
-        self._build_col_work()
+        self._col_work = {}
         self.tile_rslots = self.tile_cslots = None
         self._struct = OrianaCounts(self.n, self.m, self.nrb, self.ncb, self.nnz, self.rslots, self.cslots,
                                     ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
@@ -382,7 +395,7 @@ def factor_prep(F, logF, mask=None, mu=None, row_index=None):
 
 
 def col_pass(ct, s_cs, G, C, K):
-    w = ct.col_work
+    w = ct.col_work_for(K)
     call('oriana_col_pass', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 

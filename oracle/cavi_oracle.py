@@ -53,6 +53,29 @@ def _lib():
     return _LIB
 
 
+_LIB_OMP = None
+
+
+def zq_gap_omp(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X, nthreads):
+    """gap.py:67-80 with OpenMP over the cells (oracle/zq_kernels_omp.c): NOT the reference's behaviour (one
+    thread, gap.py:67) -- a second, labelled CPU figure for bench.py.  Raises if the OpenMP build is unavailable."""
+    global _LIB_OMP
+    if _LIB_OMP is None:
+        so = os.path.join(_HERE, 'liboracle_omp.so')
+        src = os.path.join(_HERE, 'zq_kernels_omp.c')
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(['make', '-C', _HERE, '-s', 'liboracle_omp.so'])
+        _LIB_OMP = ctypes.CDLL(so)
+        fp = ctypes.POINTER(ctypes.c_float)
+        _LIB_OMP.zq_gap_omp.argtypes = [fp] * 5 + [ctypes.c_int64] * 3 + [ctypes.c_int]
+        _LIB_OMP.zq_gap_omp.restype = ctypes.c_int
+    n, K = log_U_hat.shape
+    p = log_V_hat.shape[0]
+    a = [_f32c(Z_hat_i, (n, K)), _f32c(Z_hat_j, (p, K)), _f32c(log_U_hat), _f32c(log_V_hat, (p, K)), _f32c(X, (n, p))]
+    rc = _LIB_OMP.zq_gap_omp(*[_p(x) for x in a], n, p, K, int(nthreads))
+    assert rc == 0, rc
+
+
 def _f32c(a, shape=None):
     """The reference kernels are declared f4[:, :] C-contiguous (gap.py:67)."""
     a = np.asarray(a)

@@ -8,7 +8,9 @@
 
 namespace oriana {
 
-template <typename T> __device__ __forceinline__ bool is_nz(T v) { return v != (T)0; }
+// an entry exists iff its float32 value (what the record stores, gap.py:94) is non-zero: a float64 count that
+// rounds to 0.0f must not reserve a slot that would read as padding
+template <typename T> __device__ __forceinline__ bool is_nz(T v) { return (float)v != 0.0f; }
 
 // per-tile row / column counts -> slice offsets.  cnt[256] in LDS; thread sl < 16 owns a slice.
 __device__ __forceinline__ void slice_offsets(const uint32_t *cnt, uint32_t *slice /*[17] LDS*/, int tid) {

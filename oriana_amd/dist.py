@@ -12,7 +12,7 @@ log_U_hat (2 x K float64) -- the U update is row-local, so these partials exist 
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_rows', 'world_size', 'rank', 'all_reduce_sum', 'all_reduce_sum_async', 'sum_int']
+__all__ = ['shard_rows', 'world_size', 'rank', 'all_reduce_sum', 'all_reduce_sum_async', 'sum_int', 'SweepExchange']
 
 
 def shard_rows(n_total, rank_, world):
@@ -64,3 +64,84 @@ def sum_int(v, pg=None, device=None):
     t = torch.tensor([int(v)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
     return int(t.item())
+
+
+class SweepExchange:
+    """The ONE sum all-reduce of a sweep: a packed float32 buffer
+
+        Z_j (m K) | [Z_log (m K)] | [D_hat^T U_hat: hi (m K) | lo (m K)] | sum_i U_hat, sum_i log U_hat: hi (2 K) | lo (2 K)
+
+    The float32 segments are views the kernels write their per-shard partials into (no copy).  The float64
+    quantities travel as two float32 words, hi = float32(x) and lo = float32(x - hi): the pair holds x to
+    ~2^-48, and what the float32 all-reduce adds to it is the rounding of the `hi` sums -- the same 1e-7
+    relative level as the float32 sums of Z_j next to them (SURVEY 8e compares sharded and single-process
+    runs at 1e-6).  On a single process nothing is packed, split or reduced: `get64` hands back the very
+    tensor `put64` was given.  The ZI models need one more, small all-reduce per sweep (the column sums of
+    p_d, which depend on the post-exchange V_hat, zigap.py:131-132, 158)."""
+
+    def __init__(self, device, pg, f32_shapes, f64_shapes):
+        self.pg = pg
+        self.world = world_size(pg)
+        self.device = torch.device(device)
+        self.n_reduces = 0
+        self._seg32, self._seg64 = {}, {}
+        off = 0
+        for name, shape in f32_shapes.items():
+            cnt = 1
+            for d in shape:
+                cnt *= int(d)
+            self._seg32[name] = (off, cnt, tuple(int(d) for d in shape))
+            off += cnt
+        for name, shape in f64_shapes.items():
+            cnt = 1
+            for d in shape:
+                cnt *= int(d)
+            self._seg64[name] = (off, cnt, tuple(int(d) for d in shape))
+            off += 2 * cnt
+        self.numel = off
+        self.buf = torch.zeros(max(off, 1), dtype=torch.float32, device=self.device)
+        self.f32 = {name: self.buf[o:o + c].view(shape) for name, (o, c, shape) in self._seg32.items()}
+        self._local64 = {}
+        self._pending = None
+
+    def put64(self, name, t):
+        """Stage a float64 tensor of the declared shape (hi / lo split; kept as it is on one process)."""
+        if self.world == 1:
+            self._local64[name] = t
+            return
+        o, c, shape = self._seg64[name]
+        assert tuple(t.shape) == shape and t.dtype == torch.float64
+        flat = t.reshape(-1)
+        hi = flat.to(torch.float32)
+        self.buf[o:o + c] = hi
+        self.buf[o + c:o + 2 * c] = (flat - hi.to(torch.float64)).to(torch.float32)
+
+    def get64(self, name, out=None):
+        if self.world == 1:
+            t = self._local64[name]
+            if out is not None and out is not t:
+                out.copy_(t)
+                return out
+            return t
+        o, c, shape = self._seg64[name]
+        v = self.buf[o:o + c].to(torch.float64) + self.buf[o + c:o + 2 * c].to(torch.float64)
+        v = v.view(shape)
+        if out is not None:
+            out.copy_(v)
+            return out
+        return v
+
+    def reduce(self, async_op=False):
+        """The collective (no-op on one process).  With async_op the caller must wait()."""
+        if self.world == 1:
+            return
+        self.n_reduces += 1
+        if async_op:
+            self._pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def wait(self):
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None

@@ -399,26 +399,31 @@ def col_pass(ct, s_cs, G, C, K):
     call('oriana_col_pass', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 
-def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat):
+def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
     """GaP.compute_Z_q_expectations (reference gap.py:67-80) on the resident tiles: outputs first,
-    zero-filled by the callee, returns None."""
+    zero-filled by the callee, returns None.  `phase`: 'rows' stops once Z_hat_i is final (factor
+    preparation, row pass, slow path, row-side finalize), 'cols' does the rest (column pass, gene-side finalize):
+    the cell-side Gamma update only needs Z_hat_i, so a sharded sweep runs it between the two and has every
+    partial of its single exchange ready when the column pass ends."""
     ct, K = ws.ct, ws.K
-    _check_f32(Z_hat_i, (ct.n, K)); _check_f32(Z_hat_j, (ct.m, K))
-    _check_f32(log_U_hat, (ct.n, K)); _check_f32(log_V_hat, (ct.m, K))
     st = stream_ptr()
-    factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
-    factor_prep(ws.FV, log_V_hat, row_index=ct.col_perm)
-    Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
-    with _span(ws, 'row_pass'):
-        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None, None,
-             ptr(ws.tile_flag), K, st)
-    with _span(ws, 'fixup'):
-        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat), ptr(log_V_hat),
-             None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
-    with _span(ws, 'col_pass'):
-        col_pass(ct, ws.s_cs, ws.FU, ws.C, K)
-    call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), ct.n, K, 1, st)
-    call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
+    if phase in ('all', 'rows'):
+        _check_f32(Z_hat_i, (ct.n, K)); _check_f32(Z_hat_j, (ct.m, K))
+        _check_f32(log_U_hat, (ct.n, K)); _check_f32(log_V_hat, (ct.m, K))
+        factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
+        factor_prep(ws.FV, log_V_hat, row_index=ct.col_perm)
+        Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
+        with _span(ws, 'row_pass'):
+            call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None, None,
+                 ptr(ws.tile_flag), K, st)
+        with _span(ws, 'fixup'):
+            call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat), ptr(log_V_hat),
+                 None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
+        call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), ct.n, K, 1, st)
+    if phase in ('all', 'cols'):
+        with _span(ws, 'col_pass'):
+            col_pass(ct, ws.s_cs, ws.FU, ws.C, K)
+        call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
 
 
 def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
@@ -434,7 +439,7 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
          base, nbytes, stream_ptr())
 
 
-def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None, w_nz=None):
+def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None, w_nz=None, phase='all'):
     """The four loop nests on the resident tiles.  `w_nz` = D_hat at the stored entries (row-side
     slots, CountTiles.side_nz); None means 1, which is always the case inside the models
     (zigap.py:135 sets the dropout posterior of every non-zero count to 1 in float32):
@@ -442,36 +447,45 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
       Z_j[j,k]   = sum_i [dq[i,k]] r_ijk                       (gap.py:80; dq = D_hat[:, :K], zigap.py:94)
       Z_log[j,k] = sum_i r_ijk (lu_ik + lv_jk)                 (zigap.py:95) -- skipped when Z_log is None
     with r_ijk = x_ij e_k / sum_k e_k, e_k = exp(lu_ik + lv_jk) [S_tilde[j,k]].  Outputs first,
-    zero-filled here, float32 device tensors."""
+    zero-filled here, float32 device tensors.  `phase` as in zq_gap ('rows': everything Z_i needs; 'cols': the
+    per-gene sums; both phases must get the same arguments)."""
     ct, K = ws.ct, ws.K
     n, m = ct.n, ct.m
-    _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
     sparse = S_hat is not None
-    if sparse and ws.s_rs is None:
-        ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
-    if w_nz is not None and ws.sw_cs is None:
-        ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
-    sw_cs = ws.sw_cs if w_nz is not None else None
     st = stream_ptr()
-    factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
-    factor_prep(ws.FV, log_V_hat, mask=S_tilde, row_index=ct.col_perm)
-    Z_i.zero_(); Z_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
-    if Z_log is not None:
-        Z_log.zero_()
-    with _span(ws, 'row_pass'):
-        call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
-             ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
-    with _span(ws, 'fixup'):
-        call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs), ptr(ws.s_rs) if sparse else None,
-             ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
-             K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
-    R = ws.R
-    if sparse:
-        F2 = ws.extra('FVS', m)
-        call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
-        with _span(ws, 'row_spmm'):
-            call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), ptr(w_nz), ptr(F2), ptr(ws.R), K, st)
-    call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(R), None, ptr(ct.row_perm), n, K, 1, st)
+    if phase in ('all', 'rows'):
+        _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
+        if sparse and ws.s_rs is None:
+            ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
+        if w_nz is not None and ws.sw_cs is None:
+            ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
+    sw_cs = ws.sw_cs if w_nz is not None else None
+    if phase in ('all', 'rows'):
+        factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
+        factor_prep(ws.FV, log_V_hat, mask=S_tilde, row_index=ct.col_perm)
+        Z_i.zero_(); Z_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
+        if Z_log is not None:
+            Z_log.zero_()
+        with _span(ws, 'row_pass'):
+            call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
+                 ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
+        with _span(ws, 'fixup'):
+            call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs), ptr(ws.s_rs) if sparse else None,
+                 ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
+                 K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
+        R = ws.R
+        if sparse:
+            F2 = ws.extra('FVS', m)
+            call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
+            with _span(ws, 'row_spmm'):
+                call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), ptr(w_nz), ptr(F2), ptr(ws.R), K, st)
+        call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(R), None, ptr(ct.row_perm), n, K, 1, st)
+        if Z_log is not None:
+            # E[log U]-weighted row factor of the log sums: built NOW, from the pre-update E[log U] (the caller
+            # may run the cell-side update between the two phases)
+            call('oriana_scale_factor', ptr(ws.extra('GL', n)), ptr(ws.FU), ptr(log_U_hat), ptr(ct.row_perm), n, K, 1, st)
+    if phase == 'rows':
+        return
     # per-gene sums: weighted by D_hat[i, j] (sw), or -- zigap.py:94 -- by D_hat[i, k] on the plain s
     G, s_for_j = ws.FU, (sw_cs if sw_cs is not None else ws.s_cs)
     if dq is not None:
@@ -489,7 +503,6 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         G2 = ws.extra('GL', n)
         C2 = ws.extra('C2', m)
         C2.zero_()
-        call('oriana_scale_factor', ptr(G2), ptr(ws.FU), ptr(log_U_hat), ptr(ct.row_perm), n, K, 1, st)
         with _span(ws, 'col_pass_log'):
             col_pass(ct, s_log, G2, C2, K)
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ptr(ct.col_perm), m, K, st)

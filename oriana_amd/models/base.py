@@ -39,8 +39,13 @@ class _Buffer:
 
 
 def _is_sparse_input(c):
+    """SciPy sparse matrices and CountMatrix objects built from one (`._sparse`).  A torch sparse tensor is
+    not a supported container: say so instead of failing inside SciPy."""
     import scipy.sparse as sp
-    return sp.issparse(c) or (getattr(c, 'is_sparse', False) is True)
+    if isinstance(c, torch.Tensor) and (c.is_sparse or c.layout != torch.strided):
+        raise TypeError('torch sparse tensors are not supported: pass a SciPy sparse matrix, a dense array / tensor '
+                        'or engine.CountTiles')
+    return sp.issparse(c) or sp.issparse(getattr(c, '_sparse', None))
 
 
 class FactorModel:
@@ -77,18 +82,22 @@ class FactorModel:
         self.world = odist.world_size(process_group)
 
         X_host = None
+        # Under row sharding every rank must pack the genes in the SAME internal order (the replicated
+        # gene-side matrices of the on-device NMF start live in packed order): the per-gene counts that
+        # define the order are summed over the shards.
+        rf = (lambda t: odist.all_reduce_sum(t, process_group)) if self.world > 1 else None
         if isinstance(cmatrix, engine.CountTiles):
             self.counts = cmatrix
         elif _is_sparse_input(cmatrix):
             A = cmatrix._sparse if hasattr(cmatrix, '_sparse') else cmatrix
             X_host = A                     # the host-side initialisation reads it in sparse form
-            self.counts = engine.CountTiles.from_scipy(A, self.device)
+            self.counts = engine.CountTiles.from_scipy(A, self.device, reduce_fn=rf)
         else:
             X = cmatrix.as_array() if hasattr(cmatrix, 'as_array') else cmatrix
             if not isinstance(X, torch.Tensor):
                 X = np.asarray(X)
                 X_host = X
-            self.counts = engine.CountTiles.from_dense(X, self.device)
+            self.counts = engine.CountTiles.from_dense(X, self.device, reduce_fn=rf)
         self.n = self.counts.n
         self.m = self.p = self.counts.m
         self.n_total = int(n_total) if n_total is not None else odist.sum_int(self.n, process_group, self.device)
@@ -118,7 +127,15 @@ class FactorModel:
         self._log_U_hat = torch.empty(n, K, **f32)
         self._log_V_hat = torch.empty(m, K, **f32)
         self._Zi = torch.empty(max(n, 1), K, **f32)
-        self._Zj = torch.empty(max(m, 1), K, **f32)
+        # everything a sweep exchanges between row shards lives in ONE packed float32 buffer (dist.SweepExchange):
+        # the per-gene sums are views into it, written in place by the kernels
+        f32_seg = {'Zj': (max(m, 1), K)}
+        if self.sparse:
+            f32_seg['Zlog'] = (max(m, 1), K)
+        f64_seg = {'DtU': (m, K)} if self.zi else {}
+        f64_seg['sumU'] = (2, K)
+        self._xch = odist.SweepExchange(dev, process_group, f32_seg, f64_seg)
+        self._Zj = self._xch.f32['Zj']
         self._sumU = torch.zeros(2, K, **f64)        # [sum_i U_hat, sum_i log_U_hat]
         self._sumV = torch.zeros(2, K, **f64)
         self._ws = engine.ZWorkspace(self.counts, K, need_sw=False, need_srow=self.sparse)
@@ -195,6 +212,10 @@ class FactorModel:
         launch-bound).  The state tensors are updated in place, exactly as without the graph."""
         if self.world > 1:
             raise RuntimeError('graph capture is for single-process models (collectives are not captured)')
+        if self.zi:
+            # the lazy p_d of the ZI models is host-side state (snapshot + deferred evaluation) that a replayed
+            # graph would not refresh: model.p_d / state() would go stale
+            raise RuntimeError('graph capture is not available for the zero-inflated models (p_d is evaluated lazily on the host side)')
         if self._graph is not None:
             return self
         self._sweep()                          # warm-up: allocations, lazy scratch buffers
@@ -266,6 +287,18 @@ class FactorModel:
 
     def update_variational_parameters(self):
         raise NotImplementedError
+
+    def _exchange(self, **partials64):
+        """The one collective of a sweep: the packed buffer (per-gene float32 sums written in place by the
+        column pass, the cell-side column sums and any float64 per-gene partial handed in here) is summed over
+        the row shards.  Returns the reduced float64 partials by name."""
+        x = self._xch
+        x.put64('sumU', self._sumU)
+        for name, t in partials64.items():
+            x.put64(name, t)
+        x.reduce()
+        x.get64('sumU', out=self._sumU)
+        return {name: x.get64(name) for name in partials64}
 
     # ---- metrics (reference base.py:58-87; loglikelihood_X: sparse_zigap.py:44-51) --------------------
     # The reference defines loglikelihood_X on SparseZIGaP only (the deviances raise AttributeError on

@@ -1,7 +1,6 @@
 # -*- coding: utf-8 -*-
 """pCMF = Gamma-Poisson factor model (reference oriana/models/gap.py:14-135)."""
 from .. import engine
-from .. import dist as odist
 from .base import FactorModel
 
 __all__ = ['GaP']
@@ -20,15 +19,13 @@ class GaP(FactorModel):
 
     def update_variational_parameters(self):
         """gap.py:82-115 (E-step)."""
-        # both Z sums use the PRE-update E[log U], E[log V] (one joint pass, gap.py:89-94)
-        engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat)
-        # the only cross-shard quantities of a sweep: the per-gene sums (12 MB at C4) and the U_hat column
-        # sums.  The first does not depend on the U update, so it travels while that update runs.
-        pending = odist.all_reduce_sum_async(self._Zj, self.pg)
+        # both Z sums use the PRE-update E[log U], E[log V] (one joint pass, gap.py:89-94); the cell side only
+        # needs Z_i, so its update runs between the row pass and the column pass and every partial of the
+        # sweep's single exchange exists when the column pass ends
+        engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows')
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
         self._gamma_side('u', self._Zi, rate_vec=self._sumV[0])
-        odist.all_reduce_sum(self._sumU, self.pg)
-        if pending is not None:
-            pending.wait()
+        engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='cols')
+        self._exchange()                        # Z_j | sum_i U_hat | sum_i log U_hat: one all-reduce (12 MB at C4)
         # V_q: b1 = beta1 + Z_j ; b2 = beta2 + sum_i U_hat (NEW U_hat)                   gap.py:105-110
         self._gamma_side('v', self._Zj, rate_vec=self._sumU[0])

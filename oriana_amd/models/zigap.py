@@ -74,16 +74,19 @@ class _ZIMixin:
     def _D_times(self, V):
         """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K), f64 MFMA."""
         out = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
-        call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(V.contiguous()), self.n, self.m, self.k, 0,
-             stream_ptr())
+        with engine._span(self._ws, 'DV'):
+            call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(V.contiguous()), self.n, self.m, self.k, 0,
+                 stream_ptr())
         return out
 
     def _Dt_times(self, U):
-        """np.dot(D_hat.T, U) (zigap.py:124), summed over the row shards.  (m, K), f64 MFMA."""
+        """np.dot(D_hat.T, U) (zigap.py:124) over the LOCAL rows: the shards' partials are summed by the sweep's
+        packed exchange.  (m, K), f64 MFMA."""
         out = torch.zeros(self.m, self.k, dtype=torch.float64, device=self.device)
-        call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m, self.k, 1,
-             stream_ptr())
-        return odist.all_reduce_sum(out, self.pg)
+        with engine._span(self._ws, 'DtU'):
+            call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m, self.k, 1,
+                 stream_ptr())
+        return out
 
     def _update_D(self, V_for_d):
         """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat; one fused
@@ -91,8 +94,9 @@ class _ZIMixin:
         p_d itself is not stored: it is re-evaluated on access from a snapshot of the three inputs."""
         self._pd_sum.zero_()
         V = V_for_d.contiguous()
-        call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
-             ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, self.k, stream_ptr())
+        with engine._span(self._ws, 'D_update'):
+            call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
+                 ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, self.k, stream_ptr())
         self._pd_sum_fresh = True
         self._pd_snap = snap = (self._U_hat.clone(), V.clone(), self.pi_d.tensor.clone())
         self.p_d.defer(lambda: self._evaluate_p_d(*snap))
@@ -113,7 +117,7 @@ class _SparseMixin:
         self.p_s = Parameter(torch.ones(m, K, dtype=torch.float64, device=dev))       # sparse_gap.py:79
         self._S_hat = torch.ones(m, K, dtype=torch.float32, device=dev)
         self._S_tilde = torch.ones(m, K, dtype=torch.float32, device=dev)
-        self._Zlog = torch.zeros(max(m, 1), K, dtype=torch.float32, device=dev)
+        self._Zlog = self._xch.f32['Zlog']          # a view into the sweep's packed exchange buffer
         self._Veff = torch.zeros(m, K, dtype=torch.float64, device=dev)
         self._sumVeff = torch.zeros(K, dtype=torch.float64, device=dev)
 
@@ -180,13 +184,15 @@ class ZIGaP(_ZIMixin, FactorModel):
             # zigap.py:94 weights the per-gene sums with D_hat[i, k] (first K gene columns)
             dq = torch.empty(self.n, self.k, dtype=torch.float32, device=self.device)
             call('oriana_take_cols_f32', ptr(dq), ptr(self._D_hat), self.n, self.m, self.k, stream_ptr())
-        engine.zq(self._ws, self._Zi, self._Zj, None, self._log_U_hat, self._log_V_hat, dq=dq)
+        zq_args = (self._ws, self._Zi, self._Zj, None, self._log_U_hat, self._log_V_hat)
+        engine.zq(*zq_args, dq=dq, phase='rows')
         # U_q: a2 = alpha2 + D_hat V_hat (OLD V_hat)                                  zigap.py:115-120
         self._gamma_side('u', self._Zi, rate_mat=self._D_times(self._V_hat))
-        odist.all_reduce_sum(self._Zj, self.pg)
-        odist.all_reduce_sum(self._sumU, self.pg)
+        DtU = self._Dt_times(self._U_hat)           # local rows, NEW U_hat
+        engine.zq(*zq_args, dq=dq, phase='cols')
+        DtU = self._exchange(DtU=DtU)['DtU']        # Z_j | D_hat^T U_hat | column sums of U_hat: one all-reduce
         # V_q: b2 = beta2 + D_hat^T U_hat (NEW U_hat)                                 zigap.py:123-128
-        self._gamma_side('v', self._Zj, rate_mat=self._Dt_times(self._U_hat))
+        self._gamma_side('v', self._Zj, rate_mat=DtU)
         # D_q (NEW U_hat, NEW V_hat)                                                  zigap.py:130-136
         self._update_D(self._V_hat)
 
@@ -222,15 +228,14 @@ class SparseGaP(_SparseMixin, FactorModel):
     def update_variational_parameters(self):
         """sparse_gap.py:99-148."""
         self._threshold()                                                              # sparse_gap.py:113
-        engine.zq(self._ws, self._Zi, self._Zj, self._Zlog, self._log_U_hat, self._log_V_hat,
-                  S_tilde=self._S_tilde, S_hat=self._S_hat)
+        zq_args = (self._ws, self._Zi, self._Zj, self._Zlog, self._log_U_hat, self._log_V_hat)
+        engine.zq(*zq_args, S_tilde=self._S_tilde, S_hat=self._S_hat, phase='rows')
         # U_q: a2 = alpha2 + sum_j S_hat * Vprime_hat (OLD)                            sparse_gap.py:118-124
         self._sumVeff.zero_()
         call('oriana_colsum_f64', ptr(self._sumVeff), ptr(self._V_hat), ptr(self._S_hat), self.m, self.k, stream_ptr())
         self._gamma_side('u', self._Zi, rate_vec=self._sumVeff)
-        odist.all_reduce_sum(self._Zj, self.pg)
-        odist.all_reduce_sum(self._Zlog, self.pg)
-        odist.all_reduce_sum(self._sumU, self.pg)
+        engine.zq(*zq_args, S_tilde=self._S_tilde, S_hat=self._S_hat, phase='cols')
+        self._exchange()                            # Z_j | Z_log | column sums of U_hat: one all-reduce
         # Vprime_q: b1 = beta1 + S_hat * Z_j ; b2 = beta2 + S_hat * sum_i U_hat (NEW)  sparse_gap.py:127-132
         self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_vec=self._sumU[0], rmul=self._S_hat)
         # S_q                                                                          sparse_gap.py:134-141
@@ -271,17 +276,16 @@ class SparseZIGaP(_ZIMixin, _SparseMixin, FactorModel):
     def update_variational_parameters(self):
         """sparse_zigap.py:118-176."""
         self._threshold()
-        engine.zq(self._ws, self._Zi, self._Zj, self._Zlog, self._log_U_hat, self._log_V_hat,
-                  S_tilde=self._S_tilde, S_hat=self._S_hat)
+        zq_args = (self._ws, self._Zi, self._Zj, self._Zlog, self._log_U_hat, self._log_V_hat)
+        engine.zq(*zq_args, S_tilde=self._S_tilde, S_hat=self._S_hat, phase='rows')
         # V_hat = S_hat * Vprime_hat, computed BEFORE the updates and used again by the D update
         # (sparse_zigap.py:138, 165)
         self._compute_Veff()
         V_old = self._Veff.clone()
         self._gamma_side('u', self._Zi, rate_mat=self._D_times(V_old))                 # sparse_zigap.py:139-144
-        odist.all_reduce_sum(self._Zj, self.pg)
-        odist.all_reduce_sum(self._Zlog, self.pg)
-        odist.all_reduce_sum(self._sumU, self.pg)
-        DtU = self._Dt_times(self._U_hat)                                               # NEW U_hat, OLD D_hat
+        DtU = self._Dt_times(self._U_hat)                                               # local rows, NEW U_hat, OLD D_hat
+        engine.zq(*zq_args, S_tilde=self._S_tilde, S_hat=self._S_hat, phase='cols')
+        DtU = self._exchange(DtU=DtU)['DtU']        # Z_j | Z_log | D_hat^T U_hat | column sums of U_hat: one all-reduce
         self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_mat=DtU, rmul=self._S_hat)   # :147-152
         self._update_S(c_mat=DtU)                                                       # :154-161
         self._update_D(V_old)                                                           # :163-169

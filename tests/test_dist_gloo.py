@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
-"""Row sharding over 2 processes (gloo, CPU): the exchange the GPU models perform -- one sum
-all-reduce of the per-gene accumulators and of the U_hat / log_U_hat column sums per sweep
-(oriana_amd/dist.py) -- reproduces the unsharded sweep.  The per-shard arithmetic is done by the
+"""Row sharding over 2 processes (gloo, CPU): the exchange the GPU models perform -- ONE packed sum
+all-reduce per sweep of the per-gene accumulators and of the U_hat / log_U_hat column sums
+(oriana_amd/dist.py: SweepExchange) -- reproduces the unsharded sweep.  The per-shard arithmetic is done by the
 oracle here (no GPU in this container); the sharding bookkeeping and the collectives are the
 product code."""
 import os
@@ -47,9 +47,20 @@ def _sharded_gap_sweep(rank, world, port, path, out):
         a2 = co.clamp(np.broadcast_to(s0['alpha2'] + s0['V_hat'].sum(0), a1.shape).copy())
         U_hat = co.gamma_mean(a1, a2); log_U_hat = co.gamma_meanlog(a1, a2)
         sums = torch.from_numpy(np.stack([U_hat.sum(0), log_U_hat.astype(np.float64).sum(0)]))
-        Zj_t = torch.from_numpy(Zj)
-        odist.all_reduce_sum(Zj_t)                                      # the exchange
-        odist.all_reduce_sum(sums)
+        # the exchange: the product's packed buffer, exactly as models/gap.py drives it
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+        try:
+            xch = odist.SweepExchange('cpu', dist.group.WORLD, {'Zj': (m, K)}, {'sumU': (2, K)})
+            xch.f32['Zj'].copy_(torch.from_numpy(Zj))                   # (on the GPU the column pass writes here)
+            xch.put64('sumU', sums)
+            xch.reduce()
+            sums = xch.get64('sumU').clone()
+            Zj_t = xch.f32['Zj'].clone()
+        finally:
+            dist.all_reduce = real
+        assert calls == [m * K + 4 * K], calls                          # ONE collective: Z_j | sums (hi) | sums (lo)
         b1 = co.clamp(s0['beta1'][None, :] + Zj_t.numpy())
         b2 = co.clamp(np.broadcast_to(s0['beta2'] + sums[0].numpy(), b1.shape).copy())
         V_hat = co.gamma_mean(b1, b2); log_V_hat = co.gamma_meanlog(b1, b2)
@@ -77,3 +88,57 @@ def test_two_rank_sweep_matches_unsharded(tmp_path):
     for k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2'):
         assert err_colrel(got[k], ref[k]) < 2e-6, k
     assert np.array_equal(got['a2'] == 1e-15, ref['a2'] == 1e-15)
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oriana_amd import dist as odist
+        m, K = 37, 5
+        rng = np.random.default_rng(100 + rank)
+        zj = rng.gamma(2.0, 50.0, size=(m, K)).astype(np.float32)
+        zlog = (-rng.gamma(2.0, 500.0, size=(m, K))).astype(np.float32)
+        dtu = rng.gamma(2.0, 1e5, size=(m, K))                         # float64, magnitudes of D_hat^T U_hat
+        sums = np.stack([rng.gamma(2.0, 1e6, size=K), -rng.gamma(2.0, 1e5, size=K)])
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+        xch = odist.SweepExchange('cpu', dist.group.WORLD, {'Zj': (m, K), 'Zlog': (m, K)}, {'DtU': (m, K), 'sumU': (2, K)})
+        assert xch.numel == 2 * m * K + 2 * m * K + 4 * K
+        xch.f32['Zj'].copy_(torch.from_numpy(zj)); xch.f32['Zlog'].copy_(torch.from_numpy(zlog))
+        xch.put64('DtU', torch.from_numpy(dtu)); xch.put64('sumU', torch.from_numpy(sums))
+        xch.reduce()
+        dist.all_reduce = real
+        assert calls == [xch.numel] and xch.n_reduces == 1
+        got = dict(Zj=xch.f32['Zj'].numpy().copy(), Zlog=xch.f32['Zlog'].numpy().copy(),
+                   DtU=xch.get64('DtU').numpy().copy(), sumU=xch.get64('sumU').numpy().copy())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(Zj=zj, Zlog=zlog, DtU=dtu, sumU=sums))
+        if rank == 0:
+            exact = {k: sum(g[k].astype(np.float64) for g in gathered) for k in got}
+            np.savez(out, **{'got_' + k: v for k, v in got.items()}, **{'ref_' + k: v for k, v in exact.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_exchange_is_one_collective(tmp_path):
+    """Z_j | Z_log | D_hat^T U_hat | sum U_hat | sum log U_hat travel in ONE float32 all-reduce; the
+    float64 quantities ride as (hi, lo) float32 pairs and come back at float32-sum accuracy (<= 2e-7)."""
+    out = str(tmp_path / 'xch.npz')
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    for k in ('Zj', 'Zlog', 'DtU', 'sumU'):
+        err = np.abs(r['got_' + k] - r['ref_' + k]) / np.abs(r['ref_' + k])
+        assert err.max() < 2e-7, (k, err.max())
+
+
+def test_exchange_single_process_is_exact():
+    """On one process nothing is packed or rounded: get64 returns the float64 tensor it was given."""
+    from oriana_amd import dist as odist
+    xch = odist.SweepExchange('cpu', None, {'Zj': (3, 2)}, {'sumU': (2, 2)})
+    t = torch.tensor([[1.0 + 2 ** -40, 2.0], [3.0, 4.0]], dtype=torch.float64)
+    xch.put64('sumU', t)
+    xch.reduce()
+    assert xch.n_reduces == 0 and xch.get64('sumU') is t

@@ -136,3 +136,24 @@ def test_oracle_metrics_match_reference(path):
     # truncation moves the reference's integer-X value by less than one unit per entry
     assert abs(rd - float(g['metrics_int/reconstruction_deviance'])) < 2.0 * g['X'].size
     assert abs(ed - float(g['metrics_int/explained_deviance'])) < 1e-3
+
+
+def test_openmp_variant_agrees_with_single_thread():
+    """oracle/zq_kernels_omp.c (bench.py's labelled all-cores CPU figure) against the pinned single-thread loop
+    nest: row sums bit-identical (same per-row order), per-gene sums up to the order of the thread partials."""
+    rng = np.random.default_rng(3)
+    n, m, K = 211, 97, 9
+    X = (rng.poisson(2.0, size=(n, m)) * (rng.random((n, m)) < 0.3)).astype(np.float32)
+    lu = rng.normal(size=(n, K)).astype(np.float32)
+    lv = rng.normal(size=(m, K)).astype(np.float32)
+    Zi, Zj = np.empty((n, K), np.float32), np.empty((m, K), np.float32)
+    Zi2, Zj2 = np.empty((n, K), np.float32), np.empty((m, K), np.float32)
+    co.zq_gap(Zi, Zj, lu, lv, X)
+    try:
+        co.zq_gap_omp(Zi2, Zj2, lu, lv, X, 4)
+    except (OSError, Exception) as e:                     # no OpenMP toolchain on this host
+        if 'assert' in type(e).__name__.lower():
+            raise
+        pytest.skip('OpenMP build unavailable: %r' % (e,))
+    assert np.array_equal(Zi, Zi2)
+    assert err_colrel(Zj2, Zj) < 1e-6

@@ -130,3 +130,69 @@ def test_device_nmf_sharded_matches_single(tmp_path):
     W, H = device_nmf(engine.CountTiles.from_dense(X, 'cuda'), 5, n_iter=15, tol=0.0, seed=9)
     assert err_colrel(got['W'], W.cpu().numpy()) < 1e-4
     assert err_colrel(got['H'], H.cpu().numpy()) < 1e-4
+
+
+def _unpacked_worker(rank, world, port, X, K, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import oriana_amd.models as M
+        from oriana_amd import dist as odist
+        r0, r1 = odist.shard_rows(X.shape[0], rank, world)
+        # the shard is handed over UNPACKED (NumPy): the model packs it and must agree with the other rank on the
+        # internal gene order (base.py packed without a reduce_fn)
+        model = M.GaP(X[r0:r1], k=K, init='nmf', device=torch.device('cuda', 0), process_group=dist.group.WORLD, seed=4)
+        cp = model.counts.col_perm.cpu().numpy()
+        model.fit(2)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (cp, model.b1.asarray(), model.a1.asarray()))
+        if rank == 0:
+            assert np.array_equal(gathered[0][0], gathered[1][0]), 'ranks disagree on the gene order'
+            assert np.array_equal(gathered[0][1], gathered[1][1]), 'replicated b1 diverged between the ranks'
+            np.savez(out, b1=gathered[0][1], a1=np.concatenate([g[2] for g in gathered]))
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
+
+
+def test_unpacked_shards_with_device_nmf(tmp_path):
+    """init='nmf' on row shards given as plain arrays: every rank packs with the all-reduced gene counts, the
+    replicated gene side stays identical on the ranks and matches the single-process model."""
+    import oriana_amd.models as M
+    rng = np.random.default_rng(12)
+    dens = rng.beta(1.0, 4.0, size=330)
+    X = (rng.poisson(3.0, size=(700, 330)) * (rng.random((700, 330)) < dens)).astype(np.float32)
+    out = str(tmp_path / 'unpacked.npz')
+    mp.spawn(_unpacked_worker, args=(2, _free_port(), X, 4, out), nprocs=2, join=True)
+    got = np.load(out)
+    single = M.GaP(X, k=4, init='nmf', seed=4)
+    single.fit(2)
+    assert err_colrel(got['b1'], single.b1.asarray()) < 1e-4
+    assert err_colrel(got['a1'], single.a1.asarray()) < 1e-4
+
+
+def test_bench_self_launch_two_ranks():
+    """`python3 bench.py --gpus 2` from a bare interpreter (no torchrun): the parent starts two fresh ranks before
+    touching the GPU; with ORIANA_BENCH_ONE_GPU=1 both use cuda:0 and gloo stands in for RCCL.  One JSON line, one
+    packed collective per sweep."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORIANA_BENCH_ONE_GPU='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--workload', 'c4_eighth'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
+    assert d['config']['collectives_per_sweep'] == 1
+    assert len(d['per_rank_ms']['ranks']) == 2 and d['allreduce_ms'] > 0
+    assert d['exchange_bytes'] == (30000 * 100 + 4 * 100) * 4
+    assert 'K=100' in d['metric'] and '125k' in d['metric']

@@ -74,7 +74,7 @@ typedef struct {
 /* Kp for a given K (0 if K is out of range). */
 int64_t oriana_kpad(int64_t K);
 /* Column tiles (of 256 genes) one work-group of oriana_col_pass covers for this K: the "column block" of a work
- * item indexes groups of this many adjacent tiles (2 for K = 81..100, where one image of the row block serves two
+ * item indexes groups of this many adjacent tiles (2 for K = 85..100, where one image of the row block serves two
  * tiles; 1 otherwise; 0 if K is out of range). */
 int64_t oriana_col_block_tiles(int64_t K);
 /* Library / build identification ("oriana_hip gfx950 <version>"). */
@@ -154,6 +154,15 @@ int oriana_col_pass(const oriana_counts *cm, const float *s_cs,
                      * NULL / 0: uniform row bands. */
                     const int32_t *work, int64_t nwork,
                     void *stream);
+
+/* Deterministic debug mode of the column pass (no counterpart in the reference, which is
+ * single-threaded): every work item stores its accumulators in its own slab of `scratch`
+ * (oriana_col_pass_det_scratch_bytes(K, nwork) bytes) instead of adding them to C with float atomics, and a
+ * second kernel adds the slabs of each column block to C in work-item order.  Two runs give bit-identical C;
+ * the default path differs from it only by the order of the float32 additions.  Needs a work list. */
+int64_t oriana_col_pass_det_scratch_bytes(int64_t K, int64_t nwork);
+int oriana_col_pass_det(const oriana_counts *cm, const float *s_cs, const float *G, float *C, int64_t K,
+                        const int32_t *work, int64_t nwork, float *scratch, void *stream);
 
 /* Z[o,k] = (accumulate ? Z[o,k] : 0) + F[i,k] * R[i,k] (* mul[o,k] if mul), o = row_index ? row_index[i] : i
  * -- dense (r, K) out from padded (r, Kp) in. */

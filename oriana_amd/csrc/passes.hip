@@ -217,6 +217,13 @@ constexpr int tail_copies(int KP, int TAIL) {
     return free4 > 8 ? 8 : free4;
 }
 
+// End of a column-pass work item: add the accumulator to C with a float atomic (default), or -- deterministic
+// debug mode -- store it in the item's own slab of `Cpart`, which k_col_reduce then sums in a fixed order.
+__device__ __forceinline__ void flush_acc(float *d, float v, bool plain) {
+    if (plain) *d = v;
+    else if (v != 0.f) atomicAdd(d, v);
+}
+
 template <int G>
 struct WaveGeo {
     static constexpr int RW = 64 / G;
@@ -482,7 +489,8 @@ __global__ __launch_bounds__(1024) void k_row_spmm(oriana_counts cm, const float
 template <int G, int T4, int TAIL>
 __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float *__restrict__ s_cs,
                                                    const float *__restrict__ Gm, float *__restrict__ C,
-                                                   const int32_t *__restrict__ work, int64_t rb_per_band) {
+                                                   const int32_t *__restrict__ work, int64_t rb_per_band,
+                                                   float *__restrict__ Cpart) {
     constexpr int KP = 4 * G * T4 + G * TAIL;
     constexpr int TOFF = 4 * G * T4;
     constexpr int TREP = (G == 4) ? tail_copies(KP, TAIL) : 1;
@@ -646,16 +654,33 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
     }
 #undef ORIANA_COL_STEP
     if (col < cm.m) {
-        float *dst = C + col * KP;
+        const bool plain = Cpart != nullptr;
+        float *dst = plain ? Cpart + (item * TILE + cl) * KP : C + col * KP;
         #pragma unroll
         for (int t = 0; t < T4; ++t) {
             float *d = dst + choff[t] * 4;
-            if (acc[t].x != 0.f) atomicAdd(d + 0, acc[t].x);
-            if (acc[t].y != 0.f) atomicAdd(d + 1, acc[t].y);
-            if (acc[t].z != 0.f) atomicAdd(d + 2, acc[t].z);
-            if (acc[t].w != 0.f) atomicAdd(d + 3, acc[t].w);
+            flush_acc(d + 0, acc[t].x, plain);
+            flush_acc(d + 1, acc[t].y, plain);
+            flush_acc(d + 2, acc[t].z, plain);
+            flush_acc(d + 3, acc[t].w, plain);
         }
-        if (TAIL && acct != 0.f) atomicAdd(dst + TOFF + q, acct);
+        if (TAIL) flush_acc(dst + TOFF + q, acct, plain);
+    }
+}
+
+// deterministic debug mode: C[col, :] += sum over the work items of the column block, in item order
+__global__ __launch_bounds__(256) void k_col_reduce(float *__restrict__ C, const float *__restrict__ Cpart,
+                                                    const int32_t *__restrict__ work, int64_t nwork, int64_t m,
+                                                    int KP, int width) {
+    const int64_t blk = blockIdx.x;
+    const int ncol = width * TILE;
+    for (int idx = threadIdx.x; idx < ncol * KP; idx += 256) {
+        const int64_t col = blk * ncol + idx / KP;
+        if (col >= m) continue;
+        float acc = 0.f;
+        for (int64_t it = 0; it < nwork; ++it)
+            if (work[it * 3] == (int32_t)blk) acc += Cpart[it * ncol * KP + idx];
+        C[col * KP + (idx % KP)] += acc;
     }
 }
 
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
 }
 
 // ------------------------------------------------------------------------------------------
-// K = 81 .. 100 (Kp = 96 or 100): two lanes per row, 32 rows per wave, conflict-free LDS image
+// K = 85 .. 100 (Kp = 96 or 100): two lanes per row, 32 rows per wave, conflict-free LDS image
 // ------------------------------------------------------------------------------------------
 // What round 1's kernels lose at the headline K = 100 (profiles/r02_sq_pass_c4.json, tools/ubench/core_pass.hip):
 //   * a row of 25 float4 puts chunk groups 4, 5 on the same 64-byte bank quarters as groups 0, 1, so any
@@ -982,7 +1007,8 @@ __device__ __forceinline__ int lchunk4(int lane, int t) {
 template <int TAIL>
 __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const float *__restrict__ s_cs,
                                                         const float *__restrict__ Gm, float *__restrict__ C,
-                                                        const int32_t *__restrict__ work, int64_t rb_per_band) {
+                                                        const int32_t *__restrict__ work, int64_t rb_per_band,
+                                                        float *__restrict__ Cpart) {
     constexpr int KP = 96 + 4 * TAIL;
     constexpr int CPD = 3;
     extern __shared__ f4 lds[];
@@ -1083,123 +1109,18 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
     for (int h = 0; h < 2; ++h) {
         const int64_t col = (h ? cbB : cbA) * TILE + cl;
         if ((h == 0 || hasB) && col < cm.m) {
-            float *dst = C + col * KP;
+            const bool plain = Cpart != nullptr;
+            float *dst = plain ? Cpart + ((int64_t)blockIdx.x * 2 * TILE + h * TILE + cl) * KP : C + col * KP;
             #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const f4 a4 = h ? accB[t] : accA[t];
                 float *d = dst + gchunk4(lane, t) * 4;
-                if (a4.x != 0.f) atomicAdd(d + 0, a4.x);
-                if (a4.y != 0.f) atomicAdd(d + 1, a4.y);
-                if (a4.z != 0.f) atomicAdd(d + 2, a4.z);
-                if (a4.w != 0.f) atomicAdd(d + 3, a4.w);
+                flush_acc(d + 0, a4.x, plain);
+                flush_acc(d + 1, a4.y, plain);
+                flush_acc(d + 2, a4.z, plain);
+                flush_acc(d + 3, a4.w, plain);
             }
-            const float at = h ? actB : actA;
-            if (TAIL && at != 0.f) atomicAdd(dst + 96 + q, at);
-        }
-    }
-}
-
-// ---- column pass, variant: two lanes per column, 16 waves x 32 columns = two tiles side by side ------
-template <int TAIL>
-__global__ __launch_bounds__(1024) void k_col_pass_k100_g2(oriana_counts cm, const float *__restrict__ s_cs,
-                                                           const float *__restrict__ Gm, float *__restrict__ C,
-                                                           const int32_t *__restrict__ work, int64_t rb_per_band) {
-    constexpr int KP = 96 + 4 * TAIL;
-    constexpr int CPD = 2;
-    extern __shared__ f4 lds[];
-    const float *tails = reinterpret_cast<const float *>(lds + TILE * ROW4);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane & 1, g = (lane >> 1) & 15;
-    int64_t c2, rb0, rb1;
-    if (work) {
-        c2 = work[(int64_t)blockIdx.x * 3 + 0]; rb0 = work[(int64_t)blockIdx.x * 3 + 1]; rb1 = work[(int64_t)blockIdx.x * 3 + 2];
-    } else {
-        c2 = blockIdx.x;
-        rb0 = (int64_t)blockIdx.y * rb_per_band;
-        rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
-    }
-    const int64_t cb = c2 * 2 + (wave >> 3);                       // waves 0-7: first tile of the pair, 8-15: second
-    const bool has = cb < cm.ncb;                                  // (wave-uniform)
-    const int slA = (wave & 7) * 2;                                // lanes 0-31: slice slA, lanes 32-63: slA + 1
-    const int hi = lane >> 5;
-    const int64_t col = cb * TILE + (slA + hi) * 16 + g;
-    const int lane_off = g * 4 + 2 * q;                            // this lane's two entries inside a 64-slot iteration
-    const int toff = ((lane >> 1) & 3) * 4 + 2 * q;
-    int lidx[T4];
-    #pragma unroll
-    for (int t = 0; t < T4; ++t) lidx[t] = lchunk(lane, t);
-    f4 acc[T4];
-    f2 acct = {0.f, 0.f};
-    #pragma unroll
-    for (int t = 0; t < T4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-
-    for (int64_t rb = rb0; rb < rb1; ++rb) {
-        const int64_t t = rb * cm.ncb + (has ? cb : 0);
-        // the three slice offsets of this wave are scalars; each half wave selects its own
-        const uint32_t sA = cm.cslice[t * 17 + slA], sM = cm.cslice[t * 17 + slA + 1], sE = cm.cslice[t * 17 + slA + 2];
-        const int nitA = has ? (int)((sM - sA) >> 6) : 0, nitB = has ? (int)((sE - sM) >> 6) : 0;
-        const int niter = max(nitA, nitB);
-        const int nit = hi ? nitB : nitA;
-        const float *sb = s_cs + cm.coff[t];                       // scalar base; per-lane 32-bit offsets
-        const uint8_t *rbp = cm.ridx + cm.coff[t];
-        const uint32_t o0 = (hi ? sM : sA) + (uint32_t)lane_off;
-        const int last = (nit > 0) ? nit - 1 : 0;
-        f2 svq[CPD]; uint32_t rvq[CPD];
-        #pragma unroll
-        for (int d = 0; d < CPD; ++d) {
-            const uint32_t o = o0 + (uint32_t)((d < last) ? d : last) * 64u;
-            svq[d] = *reinterpret_cast<const f2 *>(sb + o);
-            rvq[d] = *reinterpret_cast<const uint16_t *>(rbp + o);
-        }
-        Stage<1024, TAIL> stg;
-        stg.load(Gm, rb * TILE, cm.n, tid);
-        ORIANA_SYNC();
-        stg.store(lds, tid);
-        ORIANA_SYNC();
-        for (int it = 0; it < niter; ++it) {
-            f2 svc = svq[0]; uint32_t rvc = rvq[0];
-            #pragma unroll
-            for (int d = 0; d + 1 < CPD; ++d) { svq[d] = svq[d + 1]; rvq[d] = rvq[d + 1]; }
-            const uint32_t o = o0 + (uint32_t)((it + CPD < last) ? it + CPD : last) * 64u;
-            svq[CPD - 1] = *reinterpret_cast<const f2 *>(sb + o);
-            rvq[CPD - 1] = *reinterpret_cast<const uint16_t *>(rbp + o);
-            if (it >= nit) svc = f2{0.f, 0.f};                    // the shorter slice of the wave is done
-#define ORIANA_COL_STEP2(U)                                                                           \
-            {                                                                                         \
-                const float s = pb_f32<U>((U & 1) ? svc.y : svc.x);                                   \
-                const int r = (int)((pb_u32<U>(rvc) >> ((U & 1) * 8)) & 0xFFu);                       \
-                const f4 *vrow = lds + r * ROW4;                                                      \
-                const f2 ss = {s, s};                                                                 \
-                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
-                    const f4 v = vrow[lidx[tt]];                                                      \
-                    acc[tt].xy = __builtin_elementwise_fma(ss, v.xy, acc[tt].xy);                     \
-                    acc[tt].zw = __builtin_elementwise_fma(ss, v.zw, acc[tt].zw);                     \
-                }                                                                                     \
-                if (TAIL) acct = __builtin_elementwise_fma(ss, *reinterpret_cast<const f2 *>(tails + r * (TREP * 4) + toff), acct); \
-                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(acc[tt]));  \
-                asm volatile("" : "+v"(svc.x), "+v"(svc.y), "+v"(rvc));                               \
-            }
-            ORIANA_COL_STEP2(0)
-            ORIANA_COL_STEP2(1)
-            ORIANA_COL_STEP2(2)
-            ORIANA_COL_STEP2(3)
-#undef ORIANA_COL_STEP2
-        }
-    }
-    if (has && col < cm.m) {
-        float *dst = C + col * KP;
-        #pragma unroll
-        for (int t = 0; t < T4; ++t) {
-            float *d = dst + gchunk(lane, t) * 4;
-            if (acc[t].x != 0.f) atomicAdd(d + 0, acc[t].x);
-            if (acc[t].y != 0.f) atomicAdd(d + 1, acc[t].y);
-            if (acc[t].z != 0.f) atomicAdd(d + 2, acc[t].z);
-            if (acc[t].w != 0.f) atomicAdd(d + 3, acc[t].w);
-        }
-        if (TAIL) {
-            if (acct.x != 0.f) atomicAdd(dst + 96 + 2 * q, acct.x);
-            if (acct.y != 0.f) atomicAdd(dst + 96 + 2 * q + 1, acct.y);
+            if (TAIL) flush_acc(dst + 96 + q, h ? actB : actA, plain);
         }
     }
 }
@@ -1249,7 +1170,7 @@ static inline bool pick_cfg(int64_t K, KCfg *c) {
         else return ORIANA_EKRANGE;                                                     \
     } while (0)
 
-// The K = 81..100 kernels (namespace k100) replace the generic ones for Kp = 96 / 100 unless the environment
+// The K = 85..100 kernels (namespace k100) replace the generic ones for Kp = 96 / 100 unless the environment
 // says ORIANA_PASS_IMPL=r1 (A/B measurements, tools/perf1.py).
 static bool use_k100(int G, int T4) {
     static const bool off = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && e[1] == '1'; }();
@@ -1325,19 +1246,18 @@ static int launch_row_spmm(const oriana_counts *cm, const float *s_rs, const flo
 
 template <int G, int T4, int TAIL>
 static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C,
-                           const int32_t *work, int64_t nwork, hipStream_t s) {
+                           const int32_t *work, int64_t nwork, float *Cpart, hipStream_t s) {
     constexpr int SPLIT = WaveGeo<G>::SPLIT;
     if (use_k100(G, T4)) {
         // work items / grid.x index PAIRS of column tiles (oriana_col_block_tiles = 2)
         constexpr int TL = (G == 4 && T4 == 6) ? TAIL : 0;
         const size_t lb2 = k100::image_bytes(TL);
-        static const bool g2 = [] { const char *e = getenv("ORIANA_COL_IMPL"); return e && e[0] == 'g' && e[1] == '2'; }();
-        auto kern = g2 ? k100::k_col_pass_k100_g2<TL> : k100::k_col_pass_k100<TL>;
+        auto kern = k100::k_col_pass_k100<TL>;
         int rc2 = set_lds(kern, lb2);
         if (rc2) return rc2;
         if (work) {
             if (nwork <= 0) return 0;
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(1024), lb2, s, *cm, s_cs, Gm, C, work, (int64_t)0);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(1024), lb2, s, *cm, s_cs, Gm, C, work, (int64_t)0, Cpart);
         } else {
             const int64_t ncp = (cm->ncb + 1) / 2;
             int64_t nb = (1024 + ncp - 1) / ncp;
@@ -1348,7 +1268,7 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const flo
             const int64_t per = (cm->nrb + nb - 1) / nb;
             nb = (cm->nrb + per - 1) / per;
             hipLaunchKernelGGL(kern, dim3((unsigned)ncp, (unsigned)nb), dim3(1024), lb2, s, *cm, s_cs, Gm, C,
-                               (const int32_t *)nullptr, per);
+                               (const int32_t *)nullptr, per, (float *)nullptr);
         }
         ORIANA_LAUNCH_CHECK();
         return 0;
@@ -1359,7 +1279,7 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const flo
         int rcw = set_lds(k_col_pass<G, T4, TAIL>, lbw);
         if (rcw) return rcw;
         hipLaunchKernelGGL((k_col_pass<G, T4, TAIL>), dim3((unsigned)(nwork * SPLIT)), dim3(1024), lbw, s, *cm, s_cs, Gm, C,
-                           work, (int64_t)0);
+                           work, (int64_t)0, Cpart);
         ORIANA_LAUNCH_CHECK();
         return 0;
     }
@@ -1375,7 +1295,7 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const flo
     const size_t lb = lds_bytes(G, T4, TAIL);
     int rc = set_lds(k_col_pass<G, T4, TAIL>, lb);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_col_pass<G, T4, TAIL>), grid, block, lb, s, *cm, s_cs, Gm, C, (const int32_t *)nullptr, per);
+    hipLaunchKernelGGL((k_col_pass<G, T4, TAIL>), grid, block, lb, s, *cm, s_cs, Gm, C, (const int32_t *)nullptr, per, (float *)nullptr);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
@@ -1459,9 +1379,44 @@ extern "C" int oriana_col_pass(const oriana_counts *cm, const float *s_cs, const
     if (!Gm || !C || !s_cs) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (nwork < 0 || (work == nullptr && nwork != 0)) return ORIANA_EINVAL;
-#define CALL(G, T, L) return launch_col_pass<G, T, L>(cm, s_cs, Gm, C, work, nwork, s)
+#define CALL(G, T, L) return launch_col_pass<G, T, L>(cm, s_cs, Gm, C, work, nwork, (float *)nullptr, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
+    return 0;
+}
+
+static int col_pass_partials(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C, int64_t K,
+                             const int32_t *work, int64_t nwork, float *scratch, hipStream_t s) {
+    KCfg cfg;
+    if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
+#define CALL(G, T, L) return launch_col_pass<G, T, L>(cm, s_cs, Gm, C, work, nwork, scratch, s)
+    ORIANA_FOR_CFG(cfg, CALL);
+#undef CALL
+    return 0;
+}
+
+extern "C" int64_t oriana_col_pass_det_scratch_bytes(int64_t K, int64_t nwork) {
+    const int64_t Kp = oriana_kpad(K), w = oriana_col_block_tiles(K);
+    if (Kp == 0 || nwork < 0) return 0;
+    return nwork * w * TILE * Kp * (int64_t)sizeof(float);
+}
+
+extern "C" int oriana_col_pass_det(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C, int64_t K,
+                                   const int32_t *work, int64_t nwork, float *scratch, void *stream) {
+    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
+    if (cm->n == 0 || cm->m == 0 || nwork == 0) return 0;
+    if (!Gm || !C || !s_cs || !work || nwork < 0 || !scratch) return ORIANA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // every (item, column, factor) slot of the scratch is written by exactly one lane of the item that owns it, except
+    // the columns past m and the padding lanes of partial column blocks: clear it first
+    ORIANA_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)oriana_col_pass_det_scratch_bytes(K, nwork), s));
+    int rc = col_pass_partials(cm, s_cs, Gm, C, K, work, nwork, scratch, s);
+    if (rc) return rc;
+    const int64_t w = oriana_col_block_tiles(K);
+    const int64_t nblk = (cm->ncb + w - 1) / w;
+    hipLaunchKernelGGL(k_col_reduce, dim3((unsigned)nblk), dim3(256), 0, s, C, scratch, work, nwork, cm->m,
+                       (int)oriana_kpad(K), (int)w);
+    ORIANA_LAUNCH_CHECK();
     return 0;
 }
 

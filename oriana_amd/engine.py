@@ -124,7 +124,7 @@ class CountTiles:
     def _build_col_work(self, target_items=None, width=1):
         """Work list of the column pass: (column block, row-block range) items of about equal
         COST, launched band of rows by band of rows.  A column block is `width` adjacent column tiles
-        (oriana_col_block_tiles(K): the K = 81..100 kernel serves two tiles with one image of the row block).
+        (oriana_col_block_tiles(K): the K = 85..100 kernel serves two tiles with one image of the row block).
         Genes differ widely in density, so uniform bands
         would leave the chip waiting for the densest column block; and the items that run at the same time
         should stage the SAME factor rows (at 1M cells the row-side factor is 400 MB, read once per column
@@ -394,8 +394,29 @@ def factor_prep(F, logF, mask=None, mu=None, row_index=None):
     return F
 
 
+DETERMINISTIC = os.environ.get('ORIANA_DETERMINISTIC') == '1'
+_det_scratch = {}
+
+
+def set_deterministic(flag=True):
+    """Debug mode: the per-gene sums of the column pass are combined in a fixed order (per work
+    item slabs + an ordered reduction) instead of float atomics, so two runs give bit-identical results; compare
+    against the default path to see what the atomics' order is worth (~1e-7).  Also ORIANA_DETERMINISTIC=1."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(flag)
+
+
 def col_pass(ct, s_cs, G, C, K):
     w = ct.col_work_for(K)
+    if DETERMINISTIC and w is not None:
+        nbytes = int(_lib.load().oriana_col_pass_det_scratch_bytes(int(K), int(w.shape[0])))
+        key = (ct.device, nbytes)
+        if key not in _det_scratch:
+            _det_scratch.clear()
+            _det_scratch[key] = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=ct.device)
+        call('oriana_col_pass_det', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), w.shape[0], ptr(_det_scratch[key]),
+             stream_ptr())
+        return
     call('oriana_col_pass', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 

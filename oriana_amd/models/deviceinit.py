@@ -10,8 +10,9 @@ does not exist; this module provides the same kind of start without leaving the 
   (Lee & Seung), whose two large products are the streaming passes of the CAVI kernels themselves --
   ``X H`` is ``oriana_row_spmm`` and ``X^T W`` is ``oriana_col_pass`` with the counts as scalars -- plus
   K x K Gram matrices.  It is a stand-in for an UNPINNED third-party routine (SURVEY 8c treats the NMF
-  output as an input fixture), so it is tested by its properties: non-negative factors, a loss that
-  never increases, sharding invariance.
+  output as an input fixture): it is pinned against a NumPy restatement of the same multiplicative updates
+  from the same start (oracle/nmf_oracle.py, tests/test_models_gpu.py) and by its properties -- non-negative
+  factors, a loss that never increases, sharding invariance.
 * ``random_shapes``: the ``use_factors=False`` start, ``Gamma(1)`` draws (gap.py:52, 62), from a
   device generator keyed by the GLOBAL row index, so that every sharding starts from the same state.
 """
@@ -69,12 +70,13 @@ def random_shapes(n, m, K, seed=0, device='cuda', row0=0):
     return a1, b1
 
 
-def device_nmf(counts, K, n_iter=100, tol=1e-4, seed=0, pg=None, row0=None, return_loss=False):
+def device_nmf(counts, K, n_iter=100, tol=1e-4, seed=0, pg=None, row0=None, return_loss=False, init=None):
     """W (n, K), H (m, K) float64 >= 0 with X ~ W H^T, by multiplicative updates on the packed tiles.
 
     ``counts``: engine.CountTiles of this rank's rows; under row sharding H and the K x K Gram matrices
     are all-reduced, W stays local.  Stops after ``n_iter`` sweeps or when the loss improves by less than
-    ``tol`` relative to the first sweep's improvement.  Deterministic for a given (seed, global shape)."""
+    ``tol`` relative to the first sweep's improvement.  Deterministic for a given (seed, global shape).
+    ``init``: optional (W0 (n, K), H0 (m, K)) start instead of the seeded one (oracle comparisons)."""
     ct = counts
     n, m, dev = ct.n, ct.m, ct.device
     Kp = engine.kpad(K)
@@ -109,8 +111,13 @@ def device_nmf(counts, K, n_iter=100, tol=1e-4, seed=0, pg=None, row0=None, retu
     # start: scikit-learn's 'random' recipe, sqrt(mean(X) / K) |N(0, 1)|, keyed by global rows
     scale = (mean_x / K) ** 0.5
     absn = lambda shape, g: torch.randn(shape, generator=g, device=g.device, dtype=torch.float64).abs()
-    W0 = _rows_by_global_block(n, K, row0, seed, dev, absn) * scale
-    H0 = _rows_by_global_block(m, K, 0, seed + 7919, dev, absn) * scale
+    if init is not None:
+        W0 = torch.as_tensor(init[0], dtype=torch.float64).to(dev)
+        H0 = torch.as_tensor(init[1], dtype=torch.float64).to(dev)
+        assert tuple(W0.shape) == (n, K) and tuple(H0.shape) == (m, K)
+    else:
+        W0 = _rows_by_global_block(n, K, row0, seed, dev, absn) * scale
+        H0 = _rows_by_global_block(m, K, 0, seed + 7919, dev, absn) * scale
     rp = ct.row_perm.long() if ct.row_perm is not None else None
     cp = ct.col_perm.long() if ct.col_perm is not None else None
     Wp = torch.zeros(max(n, 1), Kp, **f32)

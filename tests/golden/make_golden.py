@@ -189,9 +189,63 @@ def main_metrics():
         print('wrote', fn, {k: float(v) for k, v in out.items() if k.startswith('metrics_')})
 
 
+def generator_moments(oriana, n, m, k, z, seeds):
+    """Moments of oriana.singlecell.generation.generate_factor_matrices (generation.py:8-86) over several seeds,
+    per statistic: [mean over seeds, standard deviation over seeds].  Statistics: block / off-block means of U
+    divided by the block's own scale (so that the random choice of alpha in {100, 250} / k drops out), block /
+    off-block means of V, mean and variance of the per-gene expression probability estimated from D = (X > 0)
+    restricted to cells with Lambda >= 1, the zero fraction of X, the mean of the non-zero counts relative to the
+    mean rate."""
+    from oriana.singlecell.generation import generate_factor_matrices
+    stats = {}
+
+    def put(name, v):
+        stats.setdefault(name, []).append(float(v))
+    for seed in seeds:
+        np.random.seed(seed)
+        X, U, V, labels = generate_factor_matrices(n, m, k, zero_inflation_level=z)
+        ng = 2
+        rows = [np.arange(n)[labels == g] for g in range(ng)]
+        kcut = [0, k // ng, k]
+        m0 = int(np.round(m * 0.5))
+        vcut = [0, m0 // ng, m0]
+        # U: in-block entries have scale alpha_g, off-block (1 - theta) * mean(alpha): report ratios that do not
+        # depend on the draw of alpha
+        inb = np.concatenate([U[np.ix_(rows[g], np.arange(kcut[g], kcut[g + 1]))].ravel() for g in range(ng)])
+        offb = np.concatenate([U[np.ix_(rows[g], np.arange(kcut[1 - g], kcut[2 - g]))].ravel() for g in range(ng)])
+        put('U_off_over_in_mean', offb.mean() / inb.mean())
+        put('U_in_cv', inb.std() / inb.mean())
+        vin = np.concatenate([V[vcut[g]:vcut[g + 1], kcut[g]:kcut[g + 1]].ravel() for g in range(ng)])
+        voff_rows = np.concatenate([V[vcut[g]:vcut[g + 1], kcut[1 - g]:kcut[2 - g]].ravel() for g in range(ng)])
+        vrest = V[m0:].ravel()
+        put('V_in_mean', vin.mean())
+        put('V_off_mean', np.concatenate([voff_rows, vrest]).mean())
+        put('zero_fraction', (X == 0).mean())
+        pi_hat = (X > 0).mean(axis=0)
+        put('pi_hat_mean', pi_hat.mean())
+        put('pi_hat_var', pi_hat.var())
+        lam = U @ V.T
+        put('nonzero_mean_over_rate', X[X > 0].mean() / lam.mean())
+    return {kk: np.asarray([np.mean(v), np.std(v)]) for kk, v in stats.items()}
+
+
+def main_generator():
+    oriana = import_reference()
+    out = {'meta/n': 2000, 'meta/m': 400, 'meta/k': 10, 'meta/seeds': 24}
+    for z in (0.5, 0.1):
+        mom = generator_moments(oriana, 2000, 400, 10, z, range(24))
+        for kk, v in mom.items():
+            out['z%02d/%s' % (int(round(z * 100)), kk)] = v
+            print('z=%.2f %-26s mean %.5f  sd over seeds %.5f' % (z, kk, v[0], v[1]))
+    np.savez_compressed(os.path.join(HERE, 'generator_moments.npz'), **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':
         main_metrics()          # only the metrics fixtures (the sweep fixtures are left as they are)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'generator':
+        main_generator()        # moments of the reference's synthetic-data generator (SURVEY 8f rank 4)
     else:
         main()
         main_metrics()
+        main_generator()

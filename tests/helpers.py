@@ -12,17 +12,24 @@ PARAM_KEYS = ['alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_
 EXPECT_KEYS = ['U_hat', 'V_hat', 'log_U_hat', 'log_V_hat', 'S_hat']
 
 RTOL = 1e-5   # BASELINE.json north_star: "within 1e-5 relative on the variational parameters"
-# The Bernoulli posteriors p = sigmoid(logit(pi) - t) amplify the float32 noise of the
-# responsibility sums by |t| (up to ~35 before p saturates): two faithful float32
-# evaluations of the reference (numba vs un-jitted, glibc expf vs NumPy exp) already
-# differ by ~1e-5 absolute there, so those two keys get 1e-4 (absolute, since colmax = 1).
-KEY_RTOL = {'p_d': 1e-4, 'p_s': 1e-4, 'pi_d': 1e-4, 'pi_s': 1e-4, 'S_hat': 1e-4}
+# Achieved errors of the HIP path against the reference's golden states, all models / shapes / starts
+# (profiles/r02_parity_errors.json, tools/parity_report.py): Gamma parameters and expectations <= 1.6e-6 in this
+# metric and <= 3.3e-6 STRICTLY element-wise relative, i.e. RTOL has a 3x margin even without the column term.
+# The dropout posterior is a probability: its error is judged absolutely -- measured 1.2e-7 on p_d and 7e-10 on
+# pi_d against the reference (round 1 allowed 1e-4); the bounds below leave room for the larger Lambda of the
+# multi-tile / sharded cases (|d p_d| <= 0.25 |d Lambda|, Lambda carries the 1e-6 relative error of U_hat, V_hat).
+KEY_ATOL = {'p_d': 2e-6, 'pi_d': 1e-7}
+# The sparsity posterior p_s = sigmoid(logit(pi_s) - t), t a float32 difference of two sums of magnitude 1e4..1e6,
+# is bounded by its conditioning wherever a test can compute it (sparsity_tolerance below; measured 1.4e-4 absolute
+# against the reference, inside that bound); 1e-4 is only the fallback for comparisons of untouched initial states.
+KEY_RTOL = {'p_s': 1e-4, 'pi_s': 1e-4, 'S_hat': 1e-4}
 
 
 def golden_files(pattern='*_*.npz'):
     skip_metrics = not pattern.startswith('metrics_')
     return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern))
-                  if not f.endswith('tables.npz') and not (skip_metrics and os.path.basename(f).startswith('metrics_')))
+                  if not f.endswith('tables.npz') and not os.path.basename(f).startswith('generator_')
+                  and not (skip_metrics and os.path.basename(f).startswith('metrics_')))
 
 
 def load_golden(path):
@@ -88,9 +95,13 @@ def assert_state_close(got, ref, rtol=RTOL, keys=None, what='', ps_tol=None):
             d = np.abs(np.asarray(got[k], dtype=np.float64) - np.asarray(ref[k], dtype=np.float64))
             assert (d <= bound).all(), '%s %s: max err/bound %.3e' % (what, k, float((d / bound).max()))
             continue
-        e = err_colrel(got[k], ref[k])
-        tol = max(rtol, KEY_RTOL.get(k, 0.0))
-        assert e <= tol, '%s %s: err %.3e > %.1e' % (what, k, e, tol)
+        if k in KEY_ATOL:
+            e = float(np.max(np.abs(np.asarray(got[k], dtype=np.float64) - np.asarray(ref[k], dtype=np.float64)))) if np.size(ref[k]) else 0.0
+            assert e <= KEY_ATOL[k], '%s %s: abs err %.3e > %.1e' % (what, k, e, KEY_ATOL[k])
+        else:
+            e = err_colrel(got[k], ref[k])
+            tol = max(rtol, KEY_RTOL.get(k, 0.0))
+            assert e <= tol, '%s %s: err %.3e > %.1e' % (what, k, e, tol)
         if k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2'):
             assert np.array_equal(np.asarray(got[k]) == 1e-15, np.asarray(ref[k]) == 1e-15), \
                 '%s %s: 1e-15 clamp pattern differs' % (what, k)

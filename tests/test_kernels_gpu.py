@@ -488,3 +488,52 @@ def test_dropout_update_fused_matches_unfused(n, m, K):
     if m > 4:
         assert np.all(p1h[:, 1][Xh[:, 1] == 0] == 1e-10)
         assert np.all(p1h[:, 3] == 1.0 - 1e-10)
+
+
+@pytest.mark.parametrize('K,m', [(100, 700), (96, 300), (20, 530), (64, 513), (200, 300)])
+def test_deterministic_column_pass(eng, K, m):
+    """Debug mode of SURVEY.md section 5 (engine.set_deterministic): the per-gene sums are combined in a fixed order
+    (per work item slabs + ordered reduction) instead of float atomics: two runs are bit-identical, and the default
+    (atomic) path agrees with it to the order of float32 additions.  K = 96 / 100 take the two-tile kernel (odd and
+    even numbers of column tiles), the others the generic one (G = 4, G = 8 with two work-groups per item)."""
+    rng = np.random.default_rng(K + m)
+    n = 1500
+    dens = rng.beta(1.0, 3.0, size=m)
+    X = (rng.poisson(3.0, size=(n, m)) + 1) * (rng.random((n, m)) < dens)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    ct = eng.CountTiles.from_dense(X.astype(np.float32), 'cuda')
+    ct._col_work[int(eng._lib.load().oriana_col_block_tiles(K))] = ct._build_col_work(
+        target_items=24, width=int(eng._lib.load().oriana_col_block_tiles(K)))      # several items per column block
+    ws = eng.ZWorkspace(ct, K)
+    tlu, tlv = torch.from_numpy(lu).cuda(), torch.from_numpy(lv).cuda()
+    outs = []
+    try:
+        for det in (True, True, False):
+            eng.set_deterministic(det)
+            Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda')
+            eng.zq_gap(ws, Zi, Zj, tlu, tlv)
+            outs.append((Zi.cpu().numpy(), Zj.cpu().numpy()))
+    finally:
+        eng.set_deterministic(False)
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0], outs[1][0])
+    assert err_colrel(outs[2][1], outs[0][1]) < 1e-6
+    from oracle import cavi_oracle as co
+    rZi = np.empty((n, K), np.float32); rZj = np.empty((m, K), np.float32)
+    co.zq_gap(rZi, rZj, lu, lv, np.ascontiguousarray(X.astype(np.float32)))
+    assert err_colrel(outs[0][1], rZj) < RTOL and err_colrel(outs[0][0], rZi) < RTOL
+
+
+@pytest.mark.parametrize('K', [85, 90, 96, 97, 100])
+@pytest.mark.parametrize('m', [250, 700])
+def test_k100_kernels_shapes(eng, K, m):
+    """The K = 85..100 kernels (two lanes per row, duplicated chunk groups, two column tiles per image): Kp = 96
+    and 100, one and three column tiles (a column-tile pair with a missing second tile), ragged row blocks."""
+    rng = np.random.default_rng(K * 7 + m)
+    n = 777
+    X = (rng.poisson(2.0, size=(n, m)) + 1) * (rng.random((n, m)) < rng.beta(1.0, 2.0, size=m))
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X.astype(np.int64), lu, lv)
+    assert eng._lib.load().oriana_col_block_tiles(K) == 2
+    assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
+    np.testing.assert_allclose(Zi.sum(1), X.sum(1), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(Zj.sum(1), X.sum(0), rtol=2e-5, atol=1e-3)

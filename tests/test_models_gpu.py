@@ -94,7 +94,9 @@ def test_factors_and_attributes():
         p = getattr(M, name)
         assert p.asarray().dtype == np.float64 and p[:].shape == p.shape
     assert M.log_U_hat.dtype == np.float32 and M.U_hat.dtype == np.float64
-    assert M.UV[:].shape == (M.n, M.m)
+    UV = M.UV[:]                                   # the lazy Einsum('nk,mk->nm') node (base.py:29, gap.py:113-115)
+    assert UV.shape == (M.n, M.m) and UV.dtype == np.float64
+    np.testing.assert_allclose(UV, M.U_hat @ M.V_hat.T, rtol=1e-12, atol=0)
     assert M.p == M.m and M.dims['k'] == M.k
 
 
@@ -274,6 +276,28 @@ def test_device_nmf_properties():
     assert dense < 0.2 * total
 
 
+def test_device_nmf_matches_oracle():
+    """f2: the on-device multiplicative-update NMF against its NumPy restatement
+    (oracle/nmf_oracle.py) from the SAME start, 15 sweeps: factors within 1e-4, the losses agree."""
+    from oracle import nmf_oracle
+    from oriana_amd import engine
+    from oriana_amd.models.deviceinit import device_nmf
+    rng = np.random.default_rng(21)
+    n, m, K = 700, 390, 6
+    Wt = rng.gamma(2.0, 1.0, size=(n, K)) * (rng.random((n, K)) < 0.5)
+    Ht = rng.gamma(2.0, 1.0, size=(m, K)) * (rng.random((m, K)) < 0.5)
+    X = rng.poisson(Wt @ Ht.T).astype(np.float32)
+    scale = np.sqrt(X.mean() / K)
+    W0 = np.abs(rng.normal(size=(n, K))) * scale
+    H0 = np.abs(rng.normal(size=(m, K))) * scale
+    ct = engine.CountTiles.from_dense(X, 'cuda')
+    W, H, losses = device_nmf(ct, K, n_iter=15, tol=0.0, init=(W0, H0), return_loss=True)
+    oW, oH, olosses = nmf_oracle.nmf_mu(X, W0.astype(np.float32), H0.astype(np.float32), 15)
+    assert err_colrel(W.cpu().numpy(), oW) < 1e-4
+    assert err_colrel(H.cpu().numpy(), oH) < 1e-4
+    np.testing.assert_allclose(losses, olosses, rtol=1e-4)
+
+
 def test_models_start_on_device():
     """init='nmf' / 'random' give a working start without a host copy of X (device tensor, CountMatrix with
     a SciPy matrix); use_factors selects the NMF factors as shapes like gap.py:49-50, 59-60."""
@@ -295,6 +319,66 @@ def test_models_start_on_device():
     assert np.isfinite(z.a1.asarray()).all()
     with pytest.raises(ValueError):
         M.GaP(Xd, k=5)                                               # no host X and no init recipe
+
+
+def test_synthetic_generator_matches_reference_moments(golden_dir):
+    """f4: SyntheticCounts restates oriana/singlecell/generation.py:8-86 on the device; its
+    block means, expression probabilities (pi_d ~ Beta(1, 1/z - 1)), zero fraction and count level agree with the
+    moments captured from the reference generator itself (tests/golden/generator_moments.npz, 24 seeds) within
+    sampling error, at the reference's default z = 0.5 and at the benchmark's z = 0.1."""
+    from oriana_amd.singlecell import SyntheticCounts
+    g = np.load(os.path.join(golden_dir, 'generator_moments.npz'))
+    n, m, k = int(g['meta/n']), int(g['meta/m']), int(g['meta/k'])
+    nseed = 12
+    for z, tag in ((0.5, 'z50'), (0.1, 'z10')):
+        acc = {}
+        for seed in range(nseed):
+            gen = SyntheticCounts(n, m, k, seed=100 + seed, device='cuda', zero_inflation_level=z)
+            X = gen.chunk(0, n).cpu().numpy(); U = gen.u_chunk(0, n).cpu().numpy(); V = gen.V.cpu().numpy()
+            lab = gen.labels(0, n).cpu().numpy()
+            kc = [0, k // 2, k]; m0 = int(round(m * 0.5)); vc = [0, m0 // 2, m0]
+            inb = np.concatenate([U[lab == q][:, kc[q]:kc[q + 1]].ravel() for q in range(2)])
+            offb = np.concatenate([U[lab == q][:, kc[1 - q]:kc[2 - q]].ravel() for q in range(2)])
+            vin = np.concatenate([V[vc[q]:vc[q + 1], kc[q]:kc[q + 1]].ravel() for q in range(2)])
+            voff = np.concatenate([V[vc[q]:vc[q + 1], kc[1 - q]:kc[2 - q]].ravel() for q in range(2)] + [V[m0:].ravel()])
+            pi_hat = (X > 0).mean(axis=0)
+            st = {'U_off_over_in_mean': offb.mean() / inb.mean(), 'U_in_cv': inb.std() / inb.mean(), 'V_in_mean': vin.mean(),
+                  'V_off_mean': voff.mean(), 'zero_fraction': (X == 0).mean(), 'pi_hat_mean': pi_hat.mean(),
+                  'pi_hat_var': pi_hat.var(), 'nonzero_mean_over_rate': X[X > 0].mean() / (U @ V.T).mean()}
+            for kk, v in st.items():
+                acc.setdefault(kk, []).append(float(v))
+        for kk, v in acc.items():
+            ref_mean, ref_sd = g['%s/%s' % (tag, kk)]
+            # both sides are means over seeds: 5 combined standard errors (+ a 1 % floor for the near-deterministic ones)
+            se = ref_sd * np.sqrt(1.0 / 24 + 1.0 / nseed)
+            assert abs(np.mean(v) - ref_mean) <= 5.0 * se + 0.01 * abs(ref_mean), (tag, kk, np.mean(v), ref_mean, se)
+
+
+def test_synthetic_generator_shuffle():
+    """The cell / gene shuffle the reference leaves as a TODO (generation.py:75): same marginal statistics, the
+    labels follow the cells, the structured genes are spread over the whole gene axis, chunks stay a pure function
+    of (seed, rows) whatever the sharding."""
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, k = 3000, 500, 10
+    a = SyntheticCounts(n, m, k, seed=5, device='cuda', zero_inflation_level=0.3)
+    b = SyntheticCounts(n, m, k, seed=5, device='cuda', zero_inflation_level=0.3, shuffle=True)
+    la, lb = a.labels(0, n).cpu().numpy(), b.labels(0, n).cpu().numpy()
+    assert (np.diff(la) >= 0).all() and not (np.diff(lb) >= 0).all()          # contiguous groups vs shuffled cells
+    assert np.array_equal(np.bincount(la), np.bincount(lb))
+    # cells of a group have the same factor scale pattern as in the unshuffled generator
+    Ub = b.u_chunk(0, n).cpu().numpy()
+    big = Ub[:, :k // 2].mean(1) > Ub[:, k // 2:].mean(1)
+    assert (big == (lb == 0)).mean() > 0.95
+    # the structured genes (the large entries of V) are no longer the first half
+    Vb = b.V.cpu().numpy()
+    strong = Vb.max(1) > 3.0 * np.median(Vb.max(1))
+    assert 0.2 < strong[:m // 2].mean() / max(strong.mean(), 1e-9) < 1.8 or strong.sum() == 0
+    Xa, Xb = a.chunk(0, n).cpu().numpy(), b.chunk(0, n).cpu().numpy()
+    assert abs((Xa == 0).mean() - (Xb == 0).mean()) < 0.02
+    # shard invariance: rows [1000, 2000) generated by a shard that starts at 1000
+    c = SyntheticCounts(n, m, k, seed=5, device='cuda', zero_inflation_level=0.3, shuffle=True, row0=1000, n=1000)
+    assert np.array_equal(c.chunk(0, 1000).cpu().numpy(), Xb[1000:2000])
+    assert np.array_equal(c.labels(0, 1000).cpu().numpy(), lb[1000:2000])
 
 
 def _chunk_sums(gen, n, m):
@@ -356,8 +440,10 @@ def test_config4_full_size_properties():
     torch.cuda.empty_cache()
 
 
-def test_config3_zi_full_size_properties():
-    """BASELINE.json configs[2] (ZI-pCMF, 100,000 x 20,000, K = 50) at full size: one sweep keeps
+@pytest.mark.parametrize('quirks', [True, False], ids=['reference_quirks', 'corrected_index'])
+def test_config3_zi_full_size_properties(quirks):
+    """BASELINE.json configs[2] (ZI-pCMF, 100,000 x 20,000, K = 50) at full size, with the default
+    reference_quirks=True (the D_hat[i, k] index of zigap.py:94) and with the corrected index: one sweep keeps
     the conservation property (D_hat = 1 at every non-zero, zigap.py:135), p_d carries the
     overrides of zigap.py:133-135 exactly, pi_d = mean_i p_d (zigap.py:158)."""
     from oriana_amd import engine
@@ -371,7 +457,7 @@ def test_config3_zi_full_size_properties():
     chunk, rows, cols = _chunk_sums(gen, n, m)
     ct = engine.CountTiles.from_chunks(n, m, chunk, 8192, 'cuda')
     a1, b1 = gen.initial_shapes()
-    model = ZIGaP(ct, k=K, init=(a1, b1), device='cuda', reference_quirks=False)
+    model = ZIGaP(ct, k=K, init=(a1, b1), device='cuda', reference_quirks=quirks)
     alpha1 = model.alpha1.tensor.clone()
     model.step()
     da = (model.a1.tensor - alpha1[None, :]).sum(1)
@@ -392,6 +478,55 @@ def test_config3_zi_full_size_properties():
     torch.cuda.empty_cache()
 
 
+def test_config5_sparse_full_size():
+    """BASELINE.json configs[4] (sparse pCMF, 500,000 x 25,000, K = 64) at full size on one GPU: the first sweep
+    conserves the counts (S_hat = 1 at the start, sparse_gap.py:79), the active-factor mask S_tilde is
+    bit-identical to (p_s > tau) (sparse_gap.py:113), and after two sweeps the loop nest on a 2000-cell slab --
+    with the MODEL's E[log U], E[log V'], S_tilde, S_hat -- agrees with the oracle (sparse_gap.py:81-97)."""
+    from oracle import cavi_oracle as co
+    from oriana_amd import engine
+    from oriana_amd.models import SparseGaP
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K = 500000, 25000, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80e9:
+        pytest.skip('needs ~60 GB of free HBM')
+    gen = SyntheticCounts(n, m, K, seed=7234, device='cuda', zero_inflation_level=0.1)
+    chunk, rows, cols = _chunk_sums(gen, n, m)
+    ct = engine.CountTiles.from_chunks(n, m, chunk, 8192, 'cuda')
+    a1, b1 = gen.initial_shapes()
+    model = SparseGaP(ct, k=K, use_factors=False, init=(a1, b1), device='cuda')
+    alpha1 = model.alpha1.tensor.clone()
+    model.step()
+    da = (model.a1.tensor - alpha1[None, :]).sum(1)                  # = sum_k SZ_i with S_hat = 1
+    assert float(((da - rows).abs() / rows.clamp_min(1.0)).max()) < 2e-5
+    model.step()
+    for name in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'p_s', 'pi_s'):
+        t = getattr(model, name).tensor
+        assert torch.isfinite(t).all(), name
+    # S_tilde as the next sweep will use it: bit-exact against the host evaluation of the same p_s
+    model._threshold()
+    p_s = model.p_s.asarray()
+    assert np.array_equal(model._S_tilde.cpu().numpy(), (p_s > model.tau).astype(np.float32))
+    assert 0 < float(model._S_tilde.mean()) <= 1.0
+    # slab parity at K = 64 with the model's own factors and masks
+    r = 2000
+    Xs = gen.chunk(0, r).contiguous()
+    cts = engine.CountTiles.from_dense(Xs, 'cuda')
+    ws = engine.ZWorkspace(cts, K, need_srow=True)
+    lu = model._log_U_hat[:r].contiguous(); lv = model._log_V_hat
+    Zi = torch.empty(r, K, device='cuda'); Zj = torch.empty(m, K, device='cuda'); Zl = torch.empty(m, K, device='cuda')
+    engine.zq(ws, Zi, Zj, Zl, lu, lv, S_tilde=model._S_tilde, S_hat=model._S_hat)
+    oZi = np.empty((r, K), np.float32); oZj = np.empty((m, K), np.float32); oZl = np.empty((m, K), np.float32)
+    co.zq_sparse_gap(oZi, oZj, oZl, lu.cpu().numpy(), lv.cpu().numpy(), model._S_tilde.cpu().numpy(),
+                     model._S_hat.cpu().numpy(), np.ascontiguousarray(Xs.cpu().numpy()))
+    assert err_colrel(Zi.cpu().numpy(), oZi) < 1e-5
+    assert err_colrel(Zj.cpu().numpy(), oZj) < 1e-5
+    assert err_colrel(Zl.cpu().numpy(), oZl) < 1e-5
+    del model, ct, cts, ws
+    torch.cuda.empty_cache()
+
+
 def test_graph_replay_matches_eager():
     """A sweep captured in a hipGraph and replayed gives the eager sweeps' state."""
     g = load_golden(golden_files('gap_c1_rand.npz')[0])
@@ -403,3 +538,14 @@ def test_graph_replay_matches_eager():
     sa, sb = A.state(), B.state()
     for k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'beta2'):
         np.testing.assert_allclose(sb[k], sa[k], rtol=1e-4)
+
+
+def test_graph_capture_refused_for_zero_inflated_models():
+    """The lazy p_d of the ZI models is host-side state a replayed graph would not refresh."""
+    import oriana_amd.models as M
+    g = load_golden(golden_files('zigap_c1_rand.npz')[0])
+    Z = M.ZIGaP(g['X'], k=int(g['meta/k']), init=(g['s0/a1'], g['s0/b1']))
+    with pytest.raises(RuntimeError):
+        Z.capture_graph()
+    Z.step()                                      # the model is untouched by the refusal
+    assert np.isfinite(Z.p_d.asarray()).all()

@@ -217,11 +217,20 @@ constexpr int tail_copies(int KP, int TAIL) {
     return free4 > 8 ? 8 : free4;
 }
 
-// End of a column-pass work item: add the accumulator to C with a float atomic (default), or -- deterministic
-// debug mode -- store it in the item's own slab of `Cpart`, which k_col_reduce then sums in a fixed order.
-__device__ __forceinline__ void flush_acc(float *d, float v, bool plain) {
-    if (plain) *d = v;
-    else if (v != 0.f) atomicAdd(d, v);
+// End of a column-pass work item.  The lanes first lay their accumulators out in LDS (the image is no longer
+// needed) as the [columns][Kp] block they are in memory; then the whole work-group adds the block to C with
+// consecutive lanes on consecutive floats: 256 contiguous bytes per wave instruction, the shape global float
+// atomics run at full rate (MI355X_MICROARCH.md, global float atomics).  The register layout would give 16 rows x 4
+// dwords 16 bytes apart per instruction instead, measured ~5x slower: ~200 us per item of 512 columns, 10 % of the
+// column pass at 125,000 cells (tools/perf_col2.py).  `plain` (deterministic debug mode): the block is stored in
+// the item's own slab instead, which k_col_reduce then sums in a fixed order.
+template <int NTHREADS>
+__device__ __forceinline__ void flush_block(const float *ldsf, float *dst, int nfloats, bool plain, int tid) {
+    for (int idx = tid; idx < nfloats; idx += NTHREADS) {
+        const float v = ldsf[idx];
+        if (plain) dst[idx] = v;
+        else if (v != 0.f) atomicAdd(dst + idx, v);
+    }
 }
 
 template <int G>
@@ -653,18 +662,27 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
     }
     }
 #undef ORIANA_COL_STEP
-    if (col < cm.m) {
+    {
+        // (everything below is recomputed from the block index: nothing extra stays live across the tile loops)
         const bool plain = Cpart != nullptr;
-        float *dst = plain ? Cpart + (item * TILE + cl) * KP : C + col * KP;
-        #pragma unroll
-        for (int t = 0; t < T4; ++t) {
-            float *d = dst + choff[t] * 4;
-            flush_acc(d + 0, acc[t].x, plain);
-            flush_acc(d + 1, acc[t].y, plain);
-            flush_acc(d + 2, acc[t].z, plain);
-            flush_acc(d + 3, acc[t].w, plain);
+        float *ldsf = reinterpret_cast<float *>(lds);
+        const int64_t item2 = blockIdx.x / Geo::SPLIT;
+        const int cl0 = (int)(blockIdx.x % Geo::SPLIT) * Geo::OWN;  // first column of this work-group inside the tile
+        const int64_t cb2 = work ? (int64_t)work[item2 * 3] : item2;
+        const int cl2 = (tid >> 6) / Geo::WPS * 16 + ((tid >> 6) % Geo::WPS) * Geo::RW + (tid & 63) / G;   // column inside the work-group's range
+        ORIANA_SYNC();                                             // every wave is done with the last image
+        if (cb2 * TILE + cl0 + cl2 < cm.m) {
+            float *row = ldsf + cl2 * KP;
+            #pragma unroll
+            for (int t = 0; t < T4; ++t) *reinterpret_cast<f4 *>(row + choff[t] * 4) = acc[t];
+            if (TAIL) row[TOFF + q] = acct;
         }
-        if (TAIL) flush_acc(dst + TOFF + q, acct, plain);
+        ORIANA_SYNC();
+        const int64_t c0 = cb2 * TILE + cl0;
+        const int64_t left = cm.m - c0;
+        const int ncols = left < Geo::OWN ? (left > 0 ? (int)left : 0) : Geo::OWN;
+        float *dst = plain ? Cpart + (item2 * TILE + cl0) * KP : C + c0 * KP;
+        flush_block<1024>(ldsf, dst, ncols * KP, plain, tid);
     }
 }
 
@@ -672,15 +690,27 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
 __global__ __launch_bounds__(256) void k_col_reduce(float *__restrict__ C, const float *__restrict__ Cpart,
                                                     const int32_t *__restrict__ work, int64_t nwork, int64_t m,
                                                     int KP, int width) {
+    __shared__ int32_t list[4096];
+    __shared__ int nlist;
     const int64_t blk = blockIdx.x;
     const int ncol = width * TILE;
-    for (int idx = threadIdx.x; idx < ncol * KP; idx += 256) {
-        const int64_t col = blk * ncol + idx / KP;
-        if (col >= m) continue;
-        float acc = 0.f;
-        for (int64_t it = 0; it < nwork; ++it)
-            if (work[it * 3] == (int32_t)blk) acc += Cpart[it * ncol * KP + idx];
-        C[col * KP + (idx % KP)] += acc;
+    for (int64_t base = 0; base < nwork; base += 4096) {           // (one pass for any realistic work list)
+        if (threadIdx.x == 0) {                                   // one thread: the list keeps the items' order
+            int c = 0;
+            const int64_t end = (base + 4096 < nwork) ? base + 4096 : nwork;
+            for (int64_t it = base; it < end; ++it)
+                if (work[it * 3] == (int32_t)blk) list[c++] = (int32_t)it;
+            nlist = c;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < ncol * KP; idx += 256) {
+            const int64_t col = blk * ncol + idx / KP;
+            if (col >= m) continue;
+            float acc = 0.f;
+            for (int j = 0; j < nlist; ++j) acc += Cpart[(int64_t)list[j] * ncol * KP + idx];
+            C[col * KP + (idx % KP)] += acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -920,6 +950,10 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         ORIANA_SYNC();
         stg.store(lds, tid);
         ORIANA_SYNC();
+#ifdef ORIANA_K100_STAGGER
+        // analysis switch: the second wave of every SIMD (waves 4-7) starts a tile ORIANA_K100_STAGGER x 64 cycles late
+        if (wave >= 4) __builtin_amdgcn_s_sleep(ORIANA_K100_STAGGER);
+#endif
         for (int it = 0; it < niter; ++it) {
             const bool live = it < nit;
             uint4 cur = rawq[0];
@@ -1105,22 +1139,25 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
 #undef ORIANA_COL_RUN4
 #undef ORIANA_COL_STEP4
     const int cl = sl * 16 + (lane >> 2);
+    const bool plain = Cpart != nullptr;
+    float *ldsf = reinterpret_cast<float *>(lds);
     #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int64_t col = (h ? cbB : cbA) * TILE + cl;
-        if ((h == 0 || hasB) && col < cm.m) {
-            const bool plain = Cpart != nullptr;
-            float *dst = plain ? Cpart + ((int64_t)blockIdx.x * 2 * TILE + h * TILE + cl) * KP : C + col * KP;
+        // one tile at a time through LDS (256 x Kp floats = 100 KB), then a contiguous flush (see flush_block)
+        const int64_t c0 = (h ? cbB : cbA) * TILE;
+        ORIANA_SYNC();
+        if ((h == 0 || hasB) && c0 + cl < cm.m) {
+            float *row = ldsf + cl * KP;
             #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const f4 a4 = h ? accB[t] : accA[t];
-                float *d = dst + gchunk4(lane, t) * 4;
-                flush_acc(d + 0, a4.x, plain);
-                flush_acc(d + 1, a4.y, plain);
-                flush_acc(d + 2, a4.z, plain);
-                flush_acc(d + 3, a4.w, plain);
-            }
-            if (TAIL) flush_acc(dst + 96 + q, h ? actB : actA, plain);
+            for (int t = 0; t < 6; ++t) *reinterpret_cast<f4 *>(row + gchunk4(lane, t) * 4) = h ? accB[t] : accA[t];
+            if (TAIL) row[96 + q] = h ? actB : actA;
+        }
+        ORIANA_SYNC();
+        if (h == 0 || hasB) {
+            const int64_t left = cm.m - c0;
+            const int ncols = left < TILE ? (left > 0 ? (int)left : 0) : TILE;
+            float *dst = plain ? Cpart + ((int64_t)blockIdx.x * 2 * TILE + h * TILE) * KP : C + c0 * KP;
+            flush_block<1024>(ldsf, dst, ncols * KP, plain, tid);
         }
     }
 }

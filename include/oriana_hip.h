@@ -116,6 +116,15 @@ int oriana_pack_fill(const void *X, int xdtype, int64_t rows, int64_t m, int64_t
 int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask,
                        const int32_t *row_index,   /* F row i is built from logF row row_index[i] (NULL: i) */
                        int64_t r, int64_t K, void *stream);
+/* Both sides at once, with the validity test CENTRED on the two sides' typical shifts: only the sums
+ * lu[i,k] + lv[j,k] enter the loop nests (gap.py:74), and the iterations drift along the scale indeterminacy
+ * (U c, V / c) -- a row takes the shifted form iff its shift lies within A <= 22 of the mean shift of its side, A
+ * chosen so that every sum of two accepted shifts keeps the reference's own float32 denominator normal.  Same F as
+ * oriana_factor_prep wherever both accept a row.  maskV: S_tilde of the sparse models or NULL; stats4: 4 floats
+ * of device scratch (sum / count of the row maxima of the two sides), written here. */
+int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                            const int32_t *row_index_u, const int32_t *row_index_v,
+                            int64_t n, int64_t m, int64_t K, float *stats4, void *stream);
 
 /* ---- the responsibility pass ----------------------------------------------------------------
  * Replaces the loop nests  GaP.compute_Z_q_expectations        (oriana/models/gap.py:67-80)

@@ -46,13 +46,77 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------
 // factor preparation
 // ------------------------------------------------------------------------------------------
+// Centred validity test of the shifted form.  Only the SUMS lu_ik + lv_jk enter the loop nest, and CAVI drifts
+// along the scale indeterminacy U c, V / c: in ZI-pCMF at BASELINE configs[2] the row maxima of E[log U] climb
+// from 4 to 45 in 25 sweeps while those of E[log V] sink to -27 (scratch note in DESIGN.md) -- a test on |mu_i| and
+// |mv_j| separately then sends EVERY entry down the exact slow path (23 -> 400 ms per sweep) although every sum is
+// harmless.  With cu, cv the means of the row maxima of the two sides (k_row_stats; rows beyond +-200 are left out),
+// a row takes the shifted form iff |mu_i - cu| < A (resp. |mv_j - cv| < A), A <= 22 chosen so that every sum
+// mu_i + mv_j = (mu_i - cu) + (mv_j - cv) + (cu + cv) stays inside (SUM_LO, SUM_HI): there the reference's own
+// float32 den = exp(mu_i + mv_j) den' lies in [3e-30, 3e32] and none of its terms that matter is denormal or
+// overflowed -- the condition under which the shifted form provably reproduces gap.py:74-78.
+constexpr float SUM_LO = -45.0f, SUM_HI = 70.0f, STAT_MAX = 200.0f;
+
+struct PrepLimits { float c_own, half, dead_max; };
+__device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stats, int side) {
+    PrepLimits L = {0.0f, SHIFT_MAX, DEAD_MAX};
+    if (stats) {
+        const float cu = stats[1] > 0.f ? stats[0] / stats[1] : 0.f;
+        const float cv = stats[3] > 0.f ? stats[2] / stats[3] : 0.f;
+        // (quantised: the sums behind the means come from float atomics; their last bits must not move a row
+        //  from one path to the other between two runs)
+        const float qu = rintf(cu * 16.f) * 0.0625f, qv = rintf(cv * 16.f) * 0.0625f;
+        const float G = qu + qv;
+        float A = fminf(SHIFT_MAX, fminf(0.5f * (SUM_HI - G), 0.5f * (G - SUM_LO)));
+        if (!(A > 0.f)) A = 0.f;                       // hopeless centre: every row takes the exact path
+        L.c_own = side ? qv : qu;
+        L.half = A;
+        // a fully masked gene row multiplies exp(lu + lv) by 0: harmless as long as no such exponential overflows
+        // against an ordinary row of the other side (whose logs stay below c_other + A)
+        L.dead_max = 85.0f - ((side ? qu : qv) + A);
+    }
+    return L;
+}
+
+// sum and count of the row maxima (rows with a NaN, no active entry or |max| > STAT_MAX are left out): stats[0..1].
+// Grid-stride over the rows, one pair of atomics per work-group (every group adds to the same two words).
+__global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ stats, const float *__restrict__ logF,
+                                                   const float *__restrict__ mask, int64_t r, int K) {
+    __shared__ float bs[4], bc[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float sum = 0.f, cnt = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < r; row += (int64_t)gridDim.x * 4) {
+        const float *l = logF + row * K;
+        const float *mk = mask ? mask + row * K : nullptr;
+        float mx = -INFINITY;
+        bool bad = false, any_on = false;
+        for (int k = lane; k < K; k += 64) {
+            const float v = l[k];
+            const bool on = mk ? (mk[k] != 0.0f) : true;
+            if (on) { any_on = true; if (v != v) bad = true; mx = fmaxf(mx, v); }
+        }
+        mx = wave_max(mx);
+        bad = __any(bad);
+        any_on = __any(any_on);
+        if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; cnt += 1.f; }
+    }
+    if (lane == 0) { bs[w] = sum; bc[w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float c = bc[0] + bc[1] + bc[2] + bc[3];
+        if (c > 0.f) { atomicAdd(stats + 0, bs[0] + bs[1] + bs[2] + bs[3]); atomicAdd(stats + 1, c); }
+    }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, float *__restrict__ mu_out,
                                                      const float *__restrict__ logF, const float *__restrict__ mask,
-                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
+                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp,
+                                                     const float *__restrict__ stats, int side) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= r) return;
+    const PrepLimits lim = prep_limits(stats, side);
     const int64_t src = row_index ? (int64_t)row_index[row] : row;
     const float *l = logF + src * K;
     const float *mk = mask ? mask + src * K : nullptr;
@@ -72,15 +136,15 @@ __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, floa
     any_on = __any(any_on);
     // A row whose mask is entirely off (a gene with no active factor, sparse_gap.py:113) multiplies every
     // exponential by 0: the reference gets den == 0 -> 1 and a contribution of exactly 0 (sparse_gap.py:88-93)
-    // provided no exp(lu + lv) overflows to inf (inf * 0 = NaN).  With its logs below DEAD_MAX and the other
-    // side's shift below SHIFT_MAX that cannot happen: the row is stored as NEGATIVE zeros (a value no other
+    // provided no exp(lu + lv) overflows to inf (inf * 0 = NaN).  With its logs below dead_max that cannot happen
+    // against an ordinary row of the other side: the row is stored as NEGATIVE zeros (a value no other
     // row can hold), which the row pass of the sparse variants recognises (den == 0 and a -0.0 operand) and
     // skips without the slow path; everywhere else -0.0 behaves as 0.
-    const bool dead = (mk != nullptr) && !any_on && !bad_all && (mx_all < DEAD_MAX);
+    const bool dead = (mk != nullptr) && !any_on && !bad_all && (mx_all < lim.dead_max);
     // Rows the shifted form cannot represent faithfully get a tiny constant instead: every entry touching
     // them fails the den >= DEN_MIN test (den <= K * FILL) and is evaluated by the exact slow path, and den
     // stays non-zero, i.e. distinguishable from a dead row.
-    const bool flagged = !dead && (bad || !(fabsf(mx) < SHIFT_MAX));
+    const bool flagged = !dead && (bad || !(fabsf(mx - lim.c_own) < lim.half));
     for (int k = lane; k < Kp; k += 64) {
         float out = dead ? -0.0f : 0.0f;                // a dead row is NEGATIVE zero in every (padded) column
         if (k < K && !dead) {
@@ -945,11 +1009,16 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
             rawq[d] = uint4{0u, 0u, 0u, 0u}; wq[d] = f2{1.f, 1.f};
             if (nit > 0) { rawq[d] = recp[(int64_t)id * 32]; if (HASW) wq[d] = *reinterpret_cast<const f2 *>(w_nz + rbase + (int64_t)id * 64); }
         }
+#ifdef ORIANA_ABLATE_NOSTAGE
+        if (cb == 0)            /* analysis build: the image is staged once (wrong results, timing only) */
+#endif
+        {
         Stage<512, TAIL> stg;
         stg.load(FV, cb * TILE, cm.m, tid);
         ORIANA_SYNC();
         stg.store(lds, tid);
         ORIANA_SYNC();
+        }
 #ifdef ORIANA_K100_STAGGER
         // analysis switch: the second wave of every SIMD (waves 4-7) starts a tile ORIANA_K100_STAGGER x 64 cycles late
         if (wave >= 4) __builtin_amdgcn_s_sleep(ORIANA_K100_STAGGER);
@@ -1372,7 +1441,28 @@ extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const 
     if (r == 0) return 0;
     if (!F || !logF) return ORIANA_EINVAL;
     hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((r + 3) / 4)), dim3(256), 0, (hipStream_t)stream, F, mu,
-                       logF, mask, row_index, r, (int)K, (int)Kp);
+                       logF, mask, row_index, r, (int)K, (int)Kp, (const float *)nullptr, 0);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                                       const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
+                                       int64_t K, float *stats4, void *stream) {
+    const int64_t Kp = oriana_kpad(K);
+    if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
+    if (Kp == 0) return ORIANA_EKRANGE;
+    if (n == 0 && m == 0) return 0;
+    if ((n > 0 && (!FU || !logU)) || (m > 0 && (!FV || !logV)) || !stats4) return ORIANA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ORIANA_HIP_CHECK(hipMemsetAsync(stats4, 0, 4 * sizeof(float), s));
+    auto nblk = [](int64_t r) { const int64_t b = (r + 3) / 4; return (unsigned)(b < 1024 ? b : 1024); };
+    if (n > 0) hipLaunchKernelGGL(k_row_stats, dim3(nblk(n)), dim3(256), 0, s, stats4, logU, (const float *)nullptr, n, (int)K);
+    if (m > 0) hipLaunchKernelGGL(k_row_stats, dim3(nblk(m)), dim3(256), 0, s, stats4 + 2, logV, maskV, m, (int)K);
+    if (n > 0) hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, FU, (float *)nullptr, logU,
+                                  (const float *)nullptr, row_index_u, n, (int)K, (int)Kp, (const float *)stats4, 0);
+    if (m > 0) hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, FV, (float *)nullptr, logV,
+                                  maskV, row_index_v, m, (int)K, (int)Kp, (const float *)stats4, 1);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

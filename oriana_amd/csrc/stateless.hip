@@ -169,8 +169,8 @@ static int zq_dense(float *Zi, float *Zj, float *Zlog, const float *log_U_hat, c
         if ((rc = oriana_take_cols_f32(dq, D_hat, n, m, K, stream))) return rc;
     }
 
-    if ((rc = oriana_factor_prep(FU, nullptr, log_U_hat, nullptr, nullptr, n, K, stream))) return rc;
-    if ((rc = oriana_factor_prep(FV, nullptr, log_V_hat, S_tilde, nullptr, m, K, stream))) return rc;
+    // (the 4 floats of statistics live at the head of R until the row pass, next on the stream, overwrites it)
+    if ((rc = oriana_factor_prep_pair(FU, FV, log_U_hat, log_V_hat, S_tilde, nullptr, nullptr, n, m, K, R, stream))) return rc;
     ORIANA_HIP_CHECK(hipMemsetAsync(C, 0, sizeof(float) * m * L.Kp, s));
     ORIANA_HIP_CHECK(hipMemsetAsync(tile_flag, 0, sizeof(int32_t) * nt, s));
     if ((rc = oriana_row_pass(&cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, K, stream))) return rc;

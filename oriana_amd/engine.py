@@ -326,6 +326,7 @@ class ZWorkspace:
         self.sw_cs = torch.zeros(max(ct.cslots, 1), **f32) if need_sw else None
         self.s_rs = torch.zeros(max(ct.rslots, 1), **f32) if need_srow else None
         self.tile_flag = torch.zeros(max(ct.nrb * ct.ncb, 1), dtype=torch.int32, device=dev)
+        self.stats = torch.zeros(4, **f32)                 # sum / count of the row maxima of E[log U], E[log V]
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
 
@@ -406,6 +407,14 @@ def set_deterministic(flag=True):
     DETERMINISTIC = bool(flag)
 
 
+def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None):
+    """FU, FV of the workspace from E[log U], E[log V] (+ S_tilde), validity test centred on the typical shifts of
+    the two sides (oriana_factor_prep_pair): the sweeps drift along U c, V / c and only the sums matter."""
+    ct = ws.ct
+    call('oriana_factor_prep_pair', ptr(ws.FU), ptr(ws.FV), ptr(log_U_hat), ptr(log_V_hat), ptr(mask_v), ptr(ct.row_perm),
+         ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), stream_ptr())
+
+
 def col_pass(ct, s_cs, G, C, K):
     w = ct.col_work_for(K)
     if DETERMINISTIC and w is not None:
@@ -431,8 +440,7 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
     if phase in ('all', 'rows'):
         _check_f32(Z_hat_i, (ct.n, K)); _check_f32(Z_hat_j, (ct.m, K))
         _check_f32(log_U_hat, (ct.n, K)); _check_f32(log_V_hat, (ct.m, K))
-        factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
-        factor_prep(ws.FV, log_V_hat, row_index=ct.col_perm)
+        factor_prep_pair(ws, log_U_hat, log_V_hat)
         Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
         with _span(ws, 'row_pass'):
             call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None, None,
@@ -482,8 +490,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
     sw_cs = ws.sw_cs if w_nz is not None else None
     if phase in ('all', 'rows'):
-        factor_prep(ws.FU, log_U_hat, row_index=ct.row_perm)
-        factor_prep(ws.FV, log_V_hat, mask=S_tilde, row_index=ct.col_perm)
+        factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=S_tilde)
         Z_i.zero_(); Z_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
         if Z_log is not None:
             Z_log.zero_()

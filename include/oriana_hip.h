@@ -74,8 +74,8 @@ typedef struct {
 /* Kp for a given K (0 if K is out of range). */
 int64_t oriana_kpad(int64_t K);
 /* Column tiles (of 256 genes) one work-group of oriana_col_pass covers for this K: the "column block" of a work
- * item indexes groups of this many adjacent tiles (2 for K = 85..100, where one image of the row block serves two
- * tiles; 1 otherwise; 0 if K is out of range). */
+ * item indexes groups of this many adjacent tiles (2 for K <= 116, where one image of the row block serves two
+ * tiles; 1 for the wider K; 0 if K is out of range). */
 int64_t oriana_col_block_tiles(int64_t K);
 /* Library / build identification ("oriana_hip gfx950 <version>"). */
 const char *oriana_version(void);
@@ -118,13 +118,17 @@ int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask
                        int64_t r, int64_t K, void *stream);
 /* Both sides at once, with the validity test CENTRED on the two sides' typical shifts: only the sums
  * lu[i,k] + lv[j,k] enter the loop nests (gap.py:74), and the iterations drift along the scale indeterminacy
- * (U c, V / c) -- a row takes the shifted form iff its shift lies within A <= 22 of the mean shift of its side, A
- * chosen so that every sum of two accepted shifts keeps the reference's own float32 denominator normal.  Same F as
- * oriana_factor_prep wherever both accept a row.  maskV: S_tilde of the sparse models or NULL; stats4: 4 floats
- * of device scratch (sum / count of the row maxima of the two sides), written here. */
+ * (U c, V / c) -- a row takes the shifted form iff its shift lies within A_side of the mean shift of its side, A_u + A_v
+ * chosen (and shared in proportion to the sides' spreads) so that every sum of two accepted shifts keeps the
+ * reference's own float32 denominator normal.  Same F as
+ * oriana_factor_prep wherever both accept a row.  maskV: S_tilde of the sparse models or NULL; scratch:
+ * oriana_prep_scratch_bytes() bytes of device memory, ZEROED once before the first call (per-group partial sums of the
+ * row maxima, added up in a fixed order by the last group to finish: no float atomics, nothing to clear between
+ * calls, safe inside a captured graph). */
 int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
                             const int32_t *row_index_u, const int32_t *row_index_v,
-                            int64_t n, int64_t m, int64_t K, float *stats4, void *stream);
+                            int64_t n, int64_t m, int64_t K, float *scratch, void *stream);
+int64_t oriana_prep_scratch_bytes(void);
 
 /* ---- the responsibility pass ----------------------------------------------------------------
  * Replaces the loop nests  GaP.compute_Z_q_expectations        (oriana/models/gap.py:67-80)

@@ -34,6 +34,7 @@ _SIGS = {
     'oriana_pack_fill': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'oriana_factor_prep': (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_factor_prep_pair': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'oriana_prep_scratch_bytes': (_I, []),
     'oriana_row_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),

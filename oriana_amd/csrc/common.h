@@ -66,6 +66,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // ---- special functions, float64 (scipy.special.digamma / polygamma(1, .) restated) ------------
 // digamma for x > 0: upward recurrence to x >= 10, then the asymptotic series.
 __device__ __forceinline__ double digamma_pos(double x) {

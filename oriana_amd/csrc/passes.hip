@@ -51,7 +51,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // from 4 to 45 in 25 sweeps while those of E[log V] sink to -27 (scratch note in DESIGN.md) -- a test on |mu_i| and
 // |mv_j| separately then sends EVERY entry down the exact slow path (23 -> 400 ms per sweep) although every sum is
 // harmless.  With cu, cv the means of the row maxima of the two sides (k_row_stats; rows beyond +-200 are left out),
-// a row takes the shifted form iff |mu_i - cu| < A (resp. |mv_j - cv| < A), A <= 22 chosen so that every sum
+// a row takes the shifted form iff |mu_i - cu| < Au (resp. |mv_j - cv| < Av), Au + Av chosen so that every sum
 // mu_i + mv_j = (mu_i - cu) + (mv_j - cv) + (cu + cv) stays inside (SUM_LO, SUM_HI): there the reference's own
 // float32 den = exp(mu_i + mv_j) den' lies in [3e-30, 3e32] and none of its terms that matter is denormal or
 // overflowed -- the condition under which the shifted form provably reproduces gap.py:74-78.
@@ -61,31 +61,51 @@ struct PrepLimits { float c_own, half, dead_max; };
 __device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stats, int side) {
     PrepLimits L = {0.0f, SHIFT_MAX, DEAD_MAX};
     if (stats) {
-        const float cu = stats[1] > 0.f ? stats[0] / stats[1] : 0.f;
-        const float cv = stats[3] > 0.f ? stats[2] / stats[3] : 0.f;
-        // (quantised: the sums behind the means come from float atomics; their last bits must not move a row
-        //  from one path to the other between two runs)
+        // stats = {sum, sum of squares, count} of the row maxima of E[log U] (0..2) and of E[log V] (3..5)
+        const float nu = stats[2], nv = stats[5];
+        const float cu = nu > 0.f ? stats[0] / nu : 0.f, cv = nv > 0.f ? stats[3] / nv : 0.f;
+        const float su = nu > 0.f ? sqrtf(fmaxf(stats[1] / nu - cu * cu, 0.f)) : 0.f;
+        const float sv = nv > 0.f ? sqrtf(fmaxf(stats[4] / nv - cv * cv, 0.f)) : 0.f;
+        // (quantised to 1/16: a coarse grid keeps the centres, and with them the path of every row, stable under
+        //  small changes of the inputs)
         const float qu = rintf(cu * 16.f) * 0.0625f, qv = rintf(cv * 16.f) * 0.0625f;
         const float G = qu + qv;
-        float A = fminf(SHIFT_MAX, fminf(0.5f * (SUM_HI - G), 0.5f * (G - SUM_LO)));
-        if (!(A > 0.f)) A = 0.f;                       // hopeless centre: every row takes the exact path
+        // total half-width W available to the two sides so that every sum stays inside (SUM_LO, SUM_HI); it is
+        // shared in proportion to the sides' spreads (ZI-pCMF ends with the cells' shifts within +-1 of each other
+        // and the genes' spread over 40 units)
+        float W = fminf(SUM_HI - G, G - SUM_LO);
+        if (!(W > 0.f)) W = 0.f;                       // hopeless centre: every row takes the exact path
+        const float share = rintf(16.f * (su + 1.f) / (su + sv + 2.f)) * 0.0625f;
+        const float Au = W * share, Av = W - Au;
         L.c_own = side ? qv : qu;
-        L.half = A;
+        L.half = side ? Av : Au;
         // a fully masked gene row multiplies exp(lu + lv) by 0: harmless as long as no such exponential overflows
-        // against an ordinary row of the other side (whose logs stay below c_other + A)
-        L.dead_max = 85.0f - ((side ? qu : qv) + A);
+        // against an accepted row of the other side (whose logs stay below c_other + A_other)
+        L.dead_max = 85.0f - (side ? qu + Au : qv + Av);
     }
     return L;
 }
 
-// sum and count of the row maxima (rows with a NaN, no active entry or |max| > STAT_MAX are left out): stats[0..1].
-// Grid-stride over the rows, one pair of atomics per work-group (every group adds to the same two words).
-__global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ stats, const float *__restrict__ logF,
-                                                   const float *__restrict__ mask, int64_t r, int K) {
-    __shared__ float bs[4], bc[4];
+// sum, sum of squares and count of the row maxima (rows with a NaN, no active entry or |max| > STAT_MAX are left out),
+// both sides in one launch: blocks [0, nbu) take E[log U], the others E[log V].  Grid-stride over the rows; every
+// work-group stores its three partial sums, and the group that finishes LAST adds them up in block order and writes
+// the six results -- no float atomics, so the statistics (and with them the choice of path of every row) are the same
+// on every run, and no buffer needs clearing between calls (the last group resets the arrival counter).
+// scratch: [0..5] results {sum, sumsq, count} x {U, V}; [6] arrival counter; [8 + 3 b ...] partials of block b.
+constexpr int STATS_MAX_BLOCKS = 1024;                 // per side
+__global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, const float *__restrict__ logU, int64_t n,
+                                                   const float *__restrict__ logV, const float *__restrict__ maskV,
+                                                   int64_t m, int K, int nbu) {
+    __shared__ float bs[4], bq[4], bc[4];
+    __shared__ bool last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float sum = 0.f, cnt = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < r; row += (int64_t)gridDim.x * 4) {
+    const bool vside = (int)blockIdx.x >= nbu;
+    const float *logF = vside ? logV : logU;
+    const float *mask = vside ? maskV : nullptr;
+    const int64_t r = vside ? m : n;
+    const int64_t b0 = vside ? (int64_t)blockIdx.x - nbu : blockIdx.x, nb = vside ? (int64_t)gridDim.x - nbu : nbu;
+    float sum = 0.f, sq = 0.f, cnt = 0.f;
+    for (int64_t row = b0 * 4 + w; row < r; row += nb * 4) {
         const float *l = logF + row * K;
         const float *mk = mask ? mask + row * K : nullptr;
         float mx = -INFINITY;
@@ -98,23 +118,45 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ stats, co
         mx = wave_max(mx);
         bad = __any(bad);
         any_on = __any(any_on);
-        if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; cnt += 1.f; }
+        if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; sq += mx * mx; cnt += 1.f; }
     }
-    if (lane == 0) { bs[w] = sum; bc[w] = cnt; }
+    if (lane == 0) { bs[w] = sum; bq[w] = sq; bc[w] = cnt; }
     __syncthreads();
+    float *part = scratch + 8;
+    unsigned *arrived = (unsigned *)(scratch + 6);
     if (threadIdx.x == 0) {
-        const float c = bc[0] + bc[1] + bc[2] + bc[3];
-        if (c > 0.f) { atomicAdd(stats + 0, bs[0] + bs[1] + bs[2] + bs[3]); atomicAdd(stats + 1, c); }
+        float *pp = part + 3 * (size_t)blockIdx.x;
+        __hip_atomic_store(pp + 0, bs[0] + bs[1] + bs[2] + bs[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, bq[0] + bq[1] + bq[2] + bq[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 2, bc[0] + bc[1] + bc[2] + bc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = old + 1 == gridDim.x;
     }
+    __syncthreads();
+    if (!last) return;
+    // the last group: waves 0 / 1 add up the partials of side U / V, each lane its blocks in order, then the lanes in
+    // a fixed tree -- a fixed summation order
+    if (w < 2) {
+        const int lo = w ? nbu : 0, hi = w ? (int)gridDim.x : nbu;
+        float a = 0.f, q = 0.f, c = 0.f;
+        for (int b = lo + lane; b < hi; b += 64) {
+            a += __hip_atomic_load(part + 3 * (size_t)b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q += __hip_atomic_load(part + 3 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c += __hip_atomic_load(part + 3 * (size_t)b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a = wave_sum(a); q = wave_sum(q); c = wave_sum(c);
+        if (lane == 0) { scratch[3 * w + 0] = a; scratch[3 * w + 1] = q; scratch[3 * w + 2] = c; }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one wave per row
-__global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, float *__restrict__ mu_out,
-                                                     const float *__restrict__ logF, const float *__restrict__ mask,
-                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp,
-                                                     const float *__restrict__ stats, int side) {
+__device__ __forceinline__ void factor_prep_row(float *__restrict__ F, float *__restrict__ mu_out,
+                                                const float *__restrict__ logF, const float *__restrict__ mask,
+                                                const int32_t *__restrict__ row_index, int64_t r, int K, int Kp,
+                                                const float *__restrict__ stats, int side, int64_t block) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = block * 4 + (threadIdx.x >> 6);
     if (row >= r) return;
     const PrepLimits lim = prep_limits(stats, side);
     const int64_t src = row_index ? (int64_t)row_index[row] : row;
@@ -157,6 +199,23 @@ __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, floa
         F[row * Kp + k] = out;
     }
     if (mu_out && lane == 0) mu_out[row] = (flagged || dead) ? NAN : mx;
+}
+
+__global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, float *__restrict__ mu_out,
+                                                     const float *__restrict__ logF, const float *__restrict__ mask,
+                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
+    factor_prep_row(F, mu_out, logF, mask, row_index, r, K, Kp, nullptr, 0, blockIdx.x);
+}
+
+// both sides in one launch (blocks [0, nbu): FU, the others: FV), limits from `stats`
+__global__ __launch_bounds__(256) void k_factor_prep_pair(float *__restrict__ FU, float *__restrict__ FV,
+                                                          const float *__restrict__ logU, const float *__restrict__ logV,
+                                                          const float *__restrict__ maskV,
+                                                          const int32_t *__restrict__ riu, const int32_t *__restrict__ riv,
+                                                          int64_t n, int64_t m, int K, int Kp, int nbu,
+                                                          const float *__restrict__ stats) {
+    if ((int)blockIdx.x < nbu) factor_prep_row(FU, nullptr, logU, nullptr, riu, n, K, Kp, stats, 0, blockIdx.x);
+    else factor_prep_row(FV, nullptr, logV, maskV, riv, m, K, Kp, stats, 1, (int64_t)blockIdx.x - nbu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -592,8 +651,6 @@ __global__ __launch_bounds__(1024) void k_col_pass(oriana_counts cm, const float
     const int sl = __builtin_amdgcn_readfirstlane(part * (16 / Geo::SPLIT) + wave / Geo::WPS);
     const int h = wave % Geo::WPS;
     const int g = lane / G;
-    const int cl = sl * 16 + h * Geo::RW + g;    // column inside the 256-column block
-    const int64_t col = cb * TILE + cl;
     const int ent_lane = (h * Geo::RW + g) * 4 + ql;
     const int rot = lds_rot<G>(lane);
     const int toff_lds = TOFF + ((lane >> 2) % TREP) * 4 + q;
@@ -1090,11 +1147,9 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
     }
 }
 
-// ---- column pass: two adjacent column tiles per work-group, one image of the row block -------------
-// Four lanes per column as in k_col_pass (a 1024-thread group leaves 128 registers per lane: two lanes per column
-// would keep only two of the twelve reads of a step in flight), 16 waves = the 16 column slices of a tile; every
-// wave walks its slice of the FIRST tile of the pair and then its slice of the SECOND one against the same image
-// (two accumulator sets): half the staging, and the tile barrier waits for the sum of two slices.
+// ---- the same image read by FOUR lanes per row (column pass, k_col_pass2 below) ----------------------
+// (a 1024-thread group leaves 128 registers per lane: two lanes per column would keep only two of the twelve reads
+// of a step in flight -- measured)
 __device__ __forceinline__ int quad_class(int lane) { const int Q = lane >> 2; return ((Q & 1) << 1) | ((Q >> 1) & 1); }
 __device__ __forceinline__ int gchunk4(int lane, int t) {
     const int a = quad_class(lane), q = lane & 3;
@@ -1107,15 +1162,44 @@ __device__ __forceinline__ int lchunk4(int lane, int t) {
     return cg * 4 + q;
 }
 
-template <int TAIL>
-__global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const float *__restrict__ s_cs,
-                                                        const float *__restrict__ Gm, float *__restrict__ C,
-                                                        const int32_t *__restrict__ work, int64_t rb_per_band,
-                                                        float *__restrict__ Cpart) {
-    constexpr int KP = 96 + 4 * TAIL;
+}  // namespace k100
+
+// ------------------------------------------------------------------------------------------
+// column pass for every Kp <= 116 (four lanes per column): TWO adjacent column tiles per image
+// ------------------------------------------------------------------------------------------
+// 16 waves = the 16 column slices of a tile; every wave walks its slice of the FIRST tile of the pair and then its
+// slice of the SECOND one against the same image of the row block (two accumulator sets): half the staging of
+// k_col_pass, and the tile barrier waits for the sum of two slices.  Work items = (pair of column tiles, row-block
+// range).  Image: the duplicated-chunk-group layout of namespace k100 for Kp = 96 / 100, k_col_pass's layout
+// (rows padded to 256 bytes, rotated chunk order, tail replicated in the padding) otherwise.
+template <int T4, int TAIL>
+struct ColImage {
+    static constexpr bool DUP = (T4 == 6);
+    static constexpr int KP = 16 * T4 + 4 * TAIL, KP4 = KP / 4, TOFF = 16 * T4;
+    static constexpr int ROW4 = DUP ? k100::ROW4 : lds_stride_floats(KP) / 4;
+    static constexpr int TREP = DUP ? k100::TREP : tail_copies(KP, TAIL);
+    static constexpr int TBASE = DUP ? TILE * ROW4 * 4 : 0;             // float offset of the tail area
+    static constexpr int TSTR = DUP ? k100::TREP * 4 : ROW4 * 4;         // floats between two rows' tails
+    static constexpr size_t bytes() { return DUP ? (size_t)k100::image_bytes(TAIL) : (size_t)TILE * ROW4 * 16; }
+    __device__ static __forceinline__ int gidx(int lane, int t) {
+        return DUP ? k100::gchunk4(lane, t) : chunk_at<4, T4>(lane, lds_rot<4>(lane), t) * 4 + (lane & 3);
+    }
+    __device__ static __forceinline__ int lidx(int lane, int t) { return DUP ? k100::lchunk4(lane, t) : gidx(lane, t); }
+    __device__ static __forceinline__ int toff(int lane) {
+        return DUP ? ((lane >> 2) & 3) * 4 + (lane & 3) : TOFF + ((lane >> 2) % TREP) * 4 + (lane & 3);
+    }
+};
+
+template <int T4, int TAIL>
+__global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const float *__restrict__ s_cs,
+                                                    const float *__restrict__ Gm, float *__restrict__ C,
+                                                    const int32_t *__restrict__ work, int64_t rb_per_band,
+                                                    float *__restrict__ Cpart) {
+    using Im = ColImage<T4, TAIL>;
+    constexpr int KP = Im::KP, ROW4 = Im::ROW4;
     constexpr int CPD = 3;
     extern __shared__ f4 lds[];
-    const float *tails = reinterpret_cast<const float *>(lds + TILE * ROW4);
+    const float *tails = reinterpret_cast<const float *>(lds) + Im::TBASE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int sl = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = column slice of both tiles
     const int q = lane & 3;
@@ -1129,14 +1213,14 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
     }
     const int64_t cbA = c2 * 2, cbB = c2 * 2 + 1;
     const bool hasB = cbB < cm.ncb;
-    const int toff = ((lane >> 2) & 3) * 4 + q;
-    int lidx[6];
+    const int toff = Im::toff(lane);
+    int lidx[T4];
     #pragma unroll
-    for (int t = 0; t < 6; ++t) lidx[t] = lchunk4(lane, t);
-    f4 accA[6], accB[6];
+    for (int t = 0; t < T4; ++t) lidx[t] = Im::lidx(lane, t);
+    f4 accA[T4], accB[T4];
     float actA = 0.f, actB = 0.f;
     #pragma unroll
-    for (int t = 0; t < 6; ++t) { accA[t] = f4{0.f, 0.f, 0.f, 0.f}; accB[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < T4; ++t) { accA[t] = f4{0.f, 0.f, 0.f, 0.f}; accB[t] = f4{0.f, 0.f, 0.f, 0.f}; }
 
     // stream of one slice: (s, row index) per slot; the loads are unconditional -- an index past the slice's end is
     // clamped, and with an empty slice it reads (and discards) slots that still lie inside the tile's region, which
@@ -1164,14 +1248,14 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
                     const int r = (int)qb_u32<U>(rvc);                                                \
                     const f4 *vrow = lds + r * ROW4;                                                  \
                     const f2 ss = {s, s};                                                             \
-                    _Pragma("unroll") for (int tt = 0; tt < 6; ++tt) {                                \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
                         const f4 v = vrow[lidx[tt]];                                                  \
                         ACC[tt].xy = __builtin_elementwise_fma(ss, v.xy, ACC[tt].xy);                 \
                         ACC[tt].zw = __builtin_elementwise_fma(ss, v.zw, ACC[tt].zw);                 \
                     }                                                                                 \
-                    if (TAIL) ACT = fmaf(s, tails[r * (TREP * 4) + toff], ACT);                       \
+                    if (TAIL) ACT = fmaf(s, tails[r * Im::TSTR + toff], ACT);                         \
                     /* step fence: one step's K-vector live at a time (both accumulator sets stay in registers) */ \
-                    _Pragma("unroll") for (int tt = 0; tt < 6; ++tt) asm volatile("" : "+v"(ACC[tt]));  \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(ACC[tt]));  \
                     asm volatile("" : "+v"(svc), "+v"(rvc));                                          \
                 }
 #define ORIANA_COL_RUN4(ST, ACC, ACT)                                                                 \
@@ -1193,10 +1277,17 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
     if (rb0 < rb1) open_stream(stA, rb0 * cm.ncb + cbA, true);
     for (int64_t rb = rb0; rb < rb1; ++rb) {
         open_stream(stB, rb * cm.ncb + (hasB ? cbB : cbA), hasB);      // in flight during the first tile's loop
-        Stage<1024, TAIL> stg;
-        stg.load(Gm, rb * TILE, cm.n, tid);
-        ORIANA_SYNC();
-        stg.store(lds, tid);
+        if (Im::DUP) {
+            k100::Stage<1024, TAIL> stg;
+            stg.load(Gm, rb * TILE, cm.n, tid);
+            ORIANA_SYNC();
+            stg.store(lds, tid);
+        } else {
+            Stage<Im::KP4, Im::TREP, TILE> stg;
+            stg.load(Gm, rb * TILE, cm.n, tid);
+            ORIANA_SYNC();
+            stg.template store<ROW4>(lds, tid);
+        }
         ORIANA_SYNC();
         ORIANA_COL_RUN4(stA, accA, actA)
         // the next row block's first stream is requested before the second tile's loop: its (HBM) latency is
@@ -1212,14 +1303,14 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
     float *ldsf = reinterpret_cast<float *>(lds);
     #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        // one tile at a time through LDS (256 x Kp floats = 100 KB), then a contiguous flush (see flush_block)
+        // one tile at a time through LDS (256 x Kp floats), then a contiguous flush (see flush_block)
         const int64_t c0 = (h ? cbB : cbA) * TILE;
         ORIANA_SYNC();
         if ((h == 0 || hasB) && c0 + cl < cm.m) {
             float *row = ldsf + cl * KP;
             #pragma unroll
-            for (int t = 0; t < 6; ++t) *reinterpret_cast<f4 *>(row + gchunk4(lane, t) * 4) = h ? accB[t] : accA[t];
-            if (TAIL) row[96 + q] = h ? actB : actA;
+            for (int t = 0; t < T4; ++t) *reinterpret_cast<f4 *>(row + Im::gidx(lane, t) * 4) = h ? accB[t] : accA[t];
+            if (TAIL) row[Im::TOFF + q] = h ? actB : actA;
         }
         ORIANA_SYNC();
         if (h == 0 || hasB) {
@@ -1231,7 +1322,6 @@ __global__ __launch_bounds__(1024) void k_col_pass_k100(oriana_counts cm, const 
     }
 }
 
-}  // namespace k100
 
 // ------------------------------------------------------------------------------------------
 // dispatch on K:  Kp = 4 * G * T4
@@ -1278,10 +1368,12 @@ static inline bool pick_cfg(int64_t K, KCfg *c) {
 
 // The K = 85..100 kernels (namespace k100) replace the generic ones for Kp = 96 / 100 unless the environment
 // says ORIANA_PASS_IMPL=r1 (A/B measurements, tools/perf1.py).
-static bool use_k100(int G, int T4) {
-    static const bool off = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && e[1] == '1'; }();
-    return !off && G == 4 && T4 == 6;
+static bool round1_kernels() {
+    static const bool r1 = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && e[1] == '1'; }();
+    return r1;
 }
+static bool use_k100(int G, int T4) { return !round1_kernels() && G == 4 && T4 == 6; }      // row pass, two lanes per row
+static bool use_col2(int G) { return !round1_kernels() && G == 4; }                          // column pass, two tiles per image
 
 template <typename KernelT>
 static int set_lds(KernelT kern, size_t bytes) {
@@ -1354,11 +1446,11 @@ template <int G, int T4, int TAIL>
 static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C,
                            const int32_t *work, int64_t nwork, float *Cpart, hipStream_t s) {
     constexpr int SPLIT = WaveGeo<G>::SPLIT;
-    if (use_k100(G, T4)) {
+    if (use_col2(G)) {
         // work items / grid.x index PAIRS of column tiles (oriana_col_block_tiles = 2)
-        constexpr int TL = (G == 4 && T4 == 6) ? TAIL : 0;
-        const size_t lb2 = k100::image_bytes(TL);
-        auto kern = k100::k_col_pass_k100<TL>;
+        constexpr int T4c = (G == 4) ? T4 : 1, TLc = (G == 4) ? TAIL : 0;       // (only instantiated for G = 4)
+        const size_t lb2 = ColImage<T4c, TLc>::bytes();
+        auto kern = k_col_pass2<T4c, TLc>;
         int rc2 = set_lds(kern, lb2);
         if (rc2) return rc2;
         if (work) {
@@ -1421,7 +1513,7 @@ extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.3"; }
 extern "C" int64_t oriana_col_block_tiles(int64_t K) {
     KCfg c;
     if (!pick_cfg(K, &c)) return 0;
-    return use_k100(c.G, c.T4) ? 2 : 1;
+    return use_col2(c.G) ? 2 : 1;
 }
 
 static bool counts_ok(const oriana_counts *cm) {
@@ -1441,28 +1533,29 @@ extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const 
     if (r == 0) return 0;
     if (!F || !logF) return ORIANA_EINVAL;
     hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((r + 3) / 4)), dim3(256), 0, (hipStream_t)stream, F, mu,
-                       logF, mask, row_index, r, (int)K, (int)Kp, (const float *)nullptr, 0);
+                       logF, mask, row_index, r, (int)K, (int)Kp);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int64_t oriana_prep_scratch_bytes(void) { return (int64_t)sizeof(float) * (8 + 3 * 2 * STATS_MAX_BLOCKS); }
+
 extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
                                        const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
-                                       int64_t K, float *stats4, void *stream) {
+                                       int64_t K, float *scratch, void *stream) {
     const int64_t Kp = oriana_kpad(K);
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (Kp == 0) return ORIANA_EKRANGE;
     if (n == 0 && m == 0) return 0;
-    if ((n > 0 && (!FU || !logU)) || (m > 0 && (!FV || !logV)) || !stats4) return ORIANA_EINVAL;
+    if ((n > 0 && (!FU || !logU)) || (m > 0 && (!FV || !logV)) || !scratch) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    ORIANA_HIP_CHECK(hipMemsetAsync(stats4, 0, 4 * sizeof(float), s));
-    auto nblk = [](int64_t r) { const int64_t b = (r + 3) / 4; return (unsigned)(b < 1024 ? b : 1024); };
-    if (n > 0) hipLaunchKernelGGL(k_row_stats, dim3(nblk(n)), dim3(256), 0, s, stats4, logU, (const float *)nullptr, n, (int)K);
-    if (m > 0) hipLaunchKernelGGL(k_row_stats, dim3(nblk(m)), dim3(256), 0, s, stats4 + 2, logV, maskV, m, (int)K);
-    if (n > 0) hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, FU, (float *)nullptr, logU,
-                                  (const float *)nullptr, row_index_u, n, (int)K, (int)Kp, (const float *)stats4, 0);
-    if (m > 0) hipLaunchKernelGGL(k_factor_prep, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, FV, (float *)nullptr, logV,
-                                  maskV, row_index_v, m, (int)K, (int)Kp, (const float *)stats4, 1);
+    auto capped = [](int64_t r) { const int64_t b = (r + 3) / 4; return (int)(b < STATS_MAX_BLOCKS ? b : STATS_MAX_BLOCKS); };
+    const int sbu = capped(n), sbv = capped(m);
+    hipLaunchKernelGGL(k_row_stats, dim3((unsigned)(sbu + sbv)), dim3(256), 0, s, scratch, logU, n, logV, maskV, m, (int)K, sbu);
+    const int64_t nbu = (n + 3) / 4, nbv = (m + 3) / 4;
+    if (nbu + nbv > 0x7fffffffLL) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_factor_prep_pair, dim3((unsigned)(nbu + nbv)), dim3(256), 0, s, FU, FV, logU, logV, maskV,
+                       row_index_u, row_index_v, n, m, (int)K, (int)Kp, (int)nbu, (const float *)scratch);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t *__restrict__ off, 
 struct WsLayout {
     int64_t nt, Kp;
     size_t tile_nnz, tile_rslots, tile_cslots, roff, coff, rslice, cslice, tile_flag, totals, rowrec, ridx, s_cs,
-        FU, FV, R, C, w_nz, sw_cs, s_rs, F2, G2, C2, dq, total;
+        FU, FV, R, C, w_nz, sw_cs, s_rs, F2, G2, C2, dq, prep, total;
 };
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -76,6 +76,7 @@ static WsLayout ws_layout(int64_t n, int64_t m, int64_t K, int64_t rslot_cap, in
     L.G2 = o;          o = align256(o + sizeof(float) * n1 * L.Kp);
     L.C2 = o;          o = align256(o + sizeof(float) * m1 * L.Kp);
     L.dq = o;          o = align256(o + sizeof(float) * n1 * (K > 0 ? K : 1));
+    L.prep = o;        o = align256(o + (size_t)oriana_prep_scratch_bytes());
     L.total = o;
     return L;
 }
@@ -169,8 +170,9 @@ static int zq_dense(float *Zi, float *Zj, float *Zlog, const float *log_U_hat, c
         if ((rc = oriana_take_cols_f32(dq, D_hat, n, m, K, stream))) return rc;
     }
 
-    // (the 4 floats of statistics live at the head of R until the row pass, next on the stream, overwrites it)
-    if ((rc = oriana_factor_prep_pair(FU, FV, log_U_hat, log_V_hat, S_tilde, nullptr, nullptr, n, m, K, R, stream))) return rc;
+    float *prep = (float *)(b + L.prep);
+    ORIANA_HIP_CHECK(hipMemsetAsync(prep, 0, 8 * sizeof(float), s));            // the arrival counter
+    if ((rc = oriana_factor_prep_pair(FU, FV, log_U_hat, log_V_hat, S_tilde, nullptr, nullptr, n, m, K, prep, stream))) return rc;
     ORIANA_HIP_CHECK(hipMemsetAsync(C, 0, sizeof(float) * m * L.Kp, s));
     ORIANA_HIP_CHECK(hipMemsetAsync(tile_flag, 0, sizeof(int32_t) * nt, s));
     if ((rc = oriana_row_pass(&cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, K, stream))) return rc;

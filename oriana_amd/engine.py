@@ -124,7 +124,7 @@ class CountTiles:
     def _build_col_work(self, target_items=None, width=1):
         """Work list of the column pass: (column block, row-block range) items of about equal
         COST, launched band of rows by band of rows.  A column block is `width` adjacent column tiles
-        (oriana_col_block_tiles(K): the K = 85..100 kernel serves two tiles with one image of the row block).
+        (oriana_col_block_tiles(K): for K <= 116 the kernel serves two tiles with one image of the row block).
         Genes differ widely in density, so uniform bands
         would leave the chip waiting for the densest column block; and the items that run at the same time
         should stage the SAME factor rows (at 1M cells the row-side factor is 400 MB, read once per column
@@ -326,7 +326,8 @@ class ZWorkspace:
         self.sw_cs = torch.zeros(max(ct.cslots, 1), **f32) if need_sw else None
         self.s_rs = torch.zeros(max(ct.rslots, 1), **f32) if need_srow else None
         self.tile_flag = torch.zeros(max(ct.nrb * ct.ncb, 1), dtype=torch.int32, device=dev)
-        self.stats = torch.zeros(4, **f32)                 # sum / count of the row maxima of E[log U], E[log V]
+        # statistics of the row maxima of E[log U], E[log V] and the partial sums they are built from (zeroed ONCE)
+        self.stats = torch.zeros(int(_lib.load().oriana_prep_scratch_bytes()) // 4, **f32)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
 

@@ -24,9 +24,9 @@ def run(reps=5):
         a.record(); eng.col_pass(ct, ws.s_cs, ws.FU, ws.C, K); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
-for T in (None, 576, 1152, 2304, 4608, 9216):
+for T in [None] + [int(x) for x in os.environ.get("TARGETS", "576,1152,2304,4608,9216").split(",")]:
     ct._col_work[w] = ct._build_col_work(target_items=T, width=w)
-    for det in (False, True):
+    for det in ((False, True) if os.environ.get("DET", "1") == "1" else (False,)):
         eng.set_deterministic(det)
         print('items %5d (target %s) %s: %.3f ms' % (ct._col_work[w].shape[0], T, 'slabs+reduce' if det else 'atomics     ', run()))
 eng.set_deterministic(False)

@@ -306,6 +306,21 @@ int oriana_dropout_update_fused(double *p_d, float *D_hat, const double *U, cons
  * `out` must be initialised (zeros for a plain product).  K <= 256. */
 int oriana_dense_times_factor(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
                               int trans, void *stream);
+/* The dense work of one ZI SWEEP on the float32 matrix cores (csrc/dense_f32.hip), K <= 128 (else ORIANA_EKRANGE:
+ * use the float64 entries above).  Long sums leave the matrix core every 256 terms and end in float64; measured
+ * against the float64 entries: D_hat within 2 float32 ulp, rate terms within 3e-7 relative.
+ *
+ * oriana_dropout_sweep_fused: D_hat[n, m] = f32(sigmoid(logit(pi_d) - U V^T)) with the overrides of zigap.py:130-136
+ * (nzmask optional as above), colsum[j] += sum_i p_d[i, j] (optional, zero it first), and -- V_next / DV_next both
+ * given or both NULL -- DV_next[n, K] += D_hat V_next[m, K] from the tile of D_hat still in registers: with V_next the
+ * factor the NEXT sweep's cell update multiplies (zigap.py:116: the V_hat just updated; sparse_zigap.py:138:
+ * S_hat * Vprime_hat) that sweep has no pass over D_hat left on the cell side.  DV_next must be zeroed first. */
+int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d,
+                               const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
+                               int64_t n, int64_t m, int64_t K, void *stream);
+/* out[m, K] += D_hat^T W[n, K] (zigap.py:124), D_hat streamed once; `out` must be initialised. */
+int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
+                                    void *stream);
 /* either output may be NULL */
 int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
 int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);

@@ -255,8 +255,16 @@ class FactorModel:
         return self._log_V_hat.cpu().numpy()
 
     # ---- pieces shared by the four models ----------------------------------------------------------
+    _ver = 0
+
+    def _touch(self):
+        """Counts the writes to the expectations a product kept across sweeps depends on (V_hat, S_hat, D_hat)."""
+        self._ver += 1
+
     def _gamma_side(self, side, Z, zmul=None, rate_vec=None, rate_mat=None, rmul=None, update=True):
         """One side of update_variational_parameters + Gamma.mean / meanlog (oriana_gamma_update)."""
+        if side == 'v':
+            self._touch()
         if side == 'u':
             s1, s2, E, Elog, sums, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self._sumU, self.alpha1, self.alpha2, self.n
         else:
@@ -425,6 +433,7 @@ class FactorModel:
                      ('log_V_hat', self._log_V_hat)):
             if k in st:
                 t.copy_(torch.as_tensor(np.asarray(st[k])).to(self.device, dtype=t.dtype))
+        self._touch()
         # column sums that the next sweep reads
         self._sumU[0] = self._U_hat.sum(0); self._sumU[1] = self._log_U_hat.double().sum(0)
         odist.all_reduce_sum(self._sumU, self.pg)

@@ -6,10 +6,16 @@ The responsibility sums run on the resident non-zero tiles (engine.zq); the drop
 exactly 1 (in float32) at every non-zero count -- zigap.py:135 sets p_d[X != 0] = 1 - 1e-10 and
 Bernoulli.mean casts to float32 (bernoulli.py:45) -- so the loop nests never need D_hat[i, j] at
 the non-zeros.  The three dense contractions of the ZI models (D_hat V_hat, D_hat^T U_hat,
-U_hat V_hat^T: zigap.py:116, 124, 132) run in float64 on the matrix cores (csrc/dense_mfma.hip):
-the first two read the float32 D_hat in place, the third is fused with the sigmoid / override /
-column-sum epilogue so that Lambda is never materialised.
+U_hat V_hat^T: zigap.py:116, 124, 132) run on the matrix cores.  Inside a sweep (csrc/dense_f32.hip, K <= 128):
+float32 products whose long sums end in float64; U_hat V_hat^T is fused with the sigmoid / override / column-sum
+epilogue so that Lambda is never materialised, and the same kernel forms D_hat V_hat for the NEXT sweep from the
+tile of D_hat it is about to store -- a sweep reads D_hat once (D_hat^T U_hat) and writes it once.  The float64
+kernels (csrc/dense_mfma.hip) evaluate p_d itself on access, the metrics, K > 128, and D_hat V_hat whenever the
+product kept from the previous sweep does not apply (first sweep, state written from outside);
+ORIANA_ZI_EXACT=1 routes everything through them.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -38,6 +44,10 @@ class _ZIMixin:
         self._nzmask = torch.zeros(((n + 31) // 32) * max(m, 1), dtype=torch.int32, device=dev)
         call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._D_hat), n, m, stream_ptr())
         self._pd_sum_fresh = False
+        # float32 matrix-core path of the sweep (dense_f32.hip) and the D_hat V product it leaves for the next sweep,
+        # valid while (D_hat, V_hat, S_hat) are the tensors it was formed from: _ver counts their writes
+        self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
+        self._DV_next = None
 
     @property
     def D_hat(self):
@@ -49,6 +59,7 @@ class _ZIMixin:
         if self.p_d.materialised:
             self._D_hat.copy_(self.p_d.tensor)
             self._pd_sum_fresh = False
+            self._DV_next = None
 
     def _mstep_pi_d(self):
         """pi_d = mean(p_d, axis=0) (zigap.py:158), summed over the row shards.  The column sums
@@ -72,7 +83,12 @@ class _ZIMixin:
     _pd_snap = None
 
     def _D_times(self, V):
-        """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K), f64 MFMA."""
+        """np.dot(D_hat, V): float32 D_hat promoted to float64 (zigap.py:116).  (n, K).  Inside a run of sweeps this is
+        the product the previous sweep's D update left behind (_update_D); otherwise f64 MFMA."""
+        kept = self._DV_next
+        self._DV_next = None
+        if kept is not None and kept[1] == self._ver:
+            return kept[0]
         out = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
         with engine._span(self._ws, 'DV'):
             call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(V.contiguous()), self.n, self.m, self.k, 0,
@@ -81,22 +97,38 @@ class _ZIMixin:
 
     def _Dt_times(self, U):
         """np.dot(D_hat.T, U) (zigap.py:124) over the LOCAL rows: the shards' partials are summed by the sweep's
-        packed exchange.  (m, K), f64 MFMA."""
+        packed exchange.  (m, K)."""
         out = torch.zeros(self.m, self.k, dtype=torch.float64, device=self.device)
         with engine._span(self._ws, 'DtU'):
-            call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m, self.k, 1,
-                 stream_ptr())
+            if self._fast_dense:
+                call('oriana_dense_t_times_factor_f32', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m,
+                     self.k, stream_ptr())
+            else:
+                call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m,
+                     self.k, 1, stream_ptr())
         return out
 
-    def _update_D(self, V_for_d):
+    def _update_D(self, V_for_d, V_next=None):
         """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat; one fused
         kernel that stores D_hat and leaves the column sums of p_d for the pi_d M-step.  The float64
-        p_d itself is not stored: it is re-evaluated on access from a snapshot of the three inputs."""
+        p_d itself is not stored: it is re-evaluated on access from a snapshot of the three inputs.
+        V_next: the factor the next sweep's cell update multiplies D_hat with, as it stands now."""
         self._pd_sum.zero_()
         V = V_for_d.contiguous()
         with engine._span(self._ws, 'D_update'):
-            call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
-                 ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, self.k, stream_ptr())
+            if self._fast_dense:
+                DV = None
+                if V_next is not None:
+                    DV = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
+                    V_next = V_next.contiguous()
+                call('oriana_dropout_sweep_fused', ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
+                     ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), self.n, self.m, self.k, stream_ptr())
+            else:
+                DV = None
+                call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
+                     ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, self.k, stream_ptr())
+        self._touch()
+        self._DV_next = (DV, self._ver) if DV is not None else None
         self._pd_sum_fresh = True
         self._pd_snap = snap = (self._U_hat.clone(), V.clone(), self.pi_d.tensor.clone())
         self.p_d.defer(lambda: self._evaluate_p_d(*snap))
@@ -144,6 +176,7 @@ class _SparseMixin:
 
     def _refresh_S_hat(self):
         self._S_hat.copy_(self.p_s.tensor)
+        self._touch()
 
     def _mstep_pi_s(self):
         call('oriana_rowmean_f64', ptr(self.pi_s.tensor), ptr(self.p_s.tensor), self.m, self.k, stream_ptr())
@@ -152,6 +185,7 @@ class _SparseMixin:
         """sparse_gap.py:134-141 (uses the NEW Vprime_hat and the sums of the NEW U_hat)."""
         call('oriana_sparsity_update', ptr(self.p_s.tensor), ptr(self._S_hat), ptr(self.pi_s.tensor), ptr(self._Zlog),
              ptr(c_vec), ptr(c_mat), ptr(self._V_hat), self.m, self.k, stream_ptr())
+        self._touch()
 
 
 class ZIGaP(_ZIMixin, FactorModel):
@@ -193,10 +227,11 @@ class ZIGaP(_ZIMixin, FactorModel):
         DtU = self._exchange(DtU=DtU)['DtU']        # Z_j | D_hat^T U_hat | column sums of U_hat: one all-reduce
         # V_q: b2 = beta2 + D_hat^T U_hat (NEW U_hat)                                 zigap.py:123-128
         self._gamma_side('v', self._Zj, rate_mat=DtU)
-        # D_q (NEW U_hat, NEW V_hat)                                                  zigap.py:130-136
-        self._update_D(self._V_hat)
+        # D_q (NEW U_hat, NEW V_hat), and D_hat V_hat for the next sweep's U_q         zigap.py:130-136, 116
+        self._update_D(self._V_hat, V_next=self._V_hat)
 
     def _load_extra(self, st):
+        self._DV_next = None
         if 'p_d' in st:
             self._refresh_D_hat()
 
@@ -288,9 +323,12 @@ class SparseZIGaP(_ZIMixin, _SparseMixin, FactorModel):
         DtU = self._exchange(DtU=DtU)['DtU']        # Z_j | Z_log | D_hat^T U_hat | column sums of U_hat: one all-reduce
         self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_mat=DtU, rmul=self._S_hat)   # :147-152
         self._update_S(c_mat=DtU)                                                       # :154-161
-        self._update_D(V_old)                                                           # :163-169
+        # :163-169; the next sweep multiplies D_hat with S_hat * Vprime_hat as they stand now (:138)
+        self._compute_Veff()
+        self._update_D(V_old, V_next=self._Veff)
 
     def _load_extra(self, st):
+        self._DV_next = None
         if 'p_d' in st:
             self._refresh_D_hat()
         if 'p_s' in st:

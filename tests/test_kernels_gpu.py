@@ -490,6 +490,96 @@ def test_dropout_update_fused_matches_unfused(n, m, K):
         assert np.all(p1h[:, 3] == 1.0 - 1e-10)
 
 
+# ---- the dense work of a ZI sweep on the float32 matrix cores (csrc/dense_f32.hip) -------------------------------
+
+F32_SHAPES = [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 1024, 100), (129, 2050, 33),
+              (2000, 70, 64), (260, 300, 97), (70, 90, 128), (5000, 3001, 50), (4100, 600, 50)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,m,K', F32_SHAPES)
+def test_dense_t_times_factor_f32(n, m, K):
+    """D_hat^T U_hat (zigap.py:124) with float32 products and sums that end in float64, against the float64 product."""
+    import torch
+    from oriana_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator(device='cpu').manual_seed(n * 7 + m * 3 + K)
+    D = torch.rand(n, m, generator=g, dtype=torch.float32)
+    D[D < 0.3] = 0.0
+    W = torch.rand(n, K, generator=g, dtype=torch.float64) * 3.0
+    Dd, Wd = D.cuda(), W.cuda()
+    out = torch.zeros(m, K, dtype=torch.float64, device='cuda')
+    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(Dd), ptr(Wd), n, m, K, stream_ptr())
+    torch.cuda.synchronize()
+    ref = (D.double().t() @ W).numpy()
+    # positive terms: relative error of the sums.  256-term float32 chains (3e-7 rms each) averaged over the chunks
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-30)
+    if n >= 1000:
+        rel = np.abs(out.cpu().numpy() - ref) / np.maximum(ref, 1e-300)
+        assert np.sqrt(np.mean(rel ** 2)) < 2.5e-7
+    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(Dd), ptr(Wd), n, m, K, stream_ptr())     # accumulates
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), 2.0 * ref, rtol=1e-6, atol=1e-30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,m,K', F32_SHAPES)
+@pytest.mark.parametrize('with_next', [True, False])
+def test_dropout_sweep_fused_matches_float64(n, m, K, with_next):
+    """oriana_dropout_sweep_fused against the float64 kernels: D_hat, the column sums of p_d, and D_hat V_next."""
+    import torch
+    from oriana_amd._lib import call, ptr, stream_ptr
+    g = torch.Generator(device='cpu').manual_seed(n + 3 * m + 11 * K)
+    U = (torch.rand(n, K, generator=g, dtype=torch.float64) * 2.0).cuda()
+    V = (torch.rand(m, K, generator=g, dtype=torch.float64) * 2.0).cuda()
+    Vn = (torch.rand(m, K, generator=g, dtype=torch.float64) * 3.0).cuda()
+    pi = torch.rand(m, generator=g, dtype=torch.float64)
+    if m > 4:
+        pi[1] = 0.0
+        pi[3] = 1.0
+    pi = pi.cuda()
+    X = (torch.rand(n, m, generator=g) < 0.2).float().cuda()
+    mask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device='cuda')
+    call('oriana_nzmask_f32', ptr(mask), ptr(X), n, m, stream_ptr())
+    D1 = torch.full((n, m), -7.0, dtype=torch.float32, device='cuda')
+    cs1 = torch.zeros(m, dtype=torch.float64, device='cuda')
+    DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
+    call('oriana_dropout_sweep_fused', ptr(D1), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs1),
+         ptr(Vn) if with_next else None, ptr(DV) if with_next else None, n, m, K, stream_ptr())
+    D2 = torch.empty_like(D1)
+    cs2 = torch.zeros_like(cs1)
+    call('oriana_dropout_update_fused', None, ptr(D2), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs2), n, m, K, stream_ptr())
+    torch.cuda.synchronize()
+    d1, d2 = D1.cpu().numpy(), D2.cpu().numpy()
+    # Lambda carries K float32 roundings (<= 1e-7 K^0.5 |Lambda| absolute in the exponent), the sigmoid two more ulp
+    lam_max = float((U @ V.t()).max())
+    assert np.max(np.abs(d1 - d2) / np.maximum(d2, 1e-30) * (d2 > 1e-30)) < 4e-7 * max(1.0, lam_max)
+    np.testing.assert_allclose(d1, d2, rtol=0, atol=3e-7)
+    Xh = X.cpu().numpy()
+    assert np.all(d1[Xh != 0] == 1.0)                                     # the overrides are exact
+    if m > 4:
+        assert np.all(d1[:, 1][Xh[:, 1] == 0] == np.float32(1e-10))
+        assert np.all(d1[:, 3] == 1.0)
+    np.testing.assert_allclose(cs1.cpu().numpy(), cs2.cpu().numpy(), rtol=3e-7)
+    if with_next:
+        ref = (D1.double() @ Vn).cpu().numpy()                            # the product of the D_hat it stored
+        np.testing.assert_allclose(DV.cpu().numpy(), ref, rtol=1e-6, atol=1e-30)
+        if m >= 1000:
+            rel = np.abs(DV.cpu().numpy() - ref) / np.maximum(ref, 1e-300)
+            assert np.sqrt(np.mean(rel ** 2)) < 2.5e-7
+
+
+@pytest.mark.gpu
+def test_f32_dense_entries_reject_large_K():
+    import torch
+    from oriana_amd import _lib
+    from oriana_amd._lib import ptr
+    t = torch.zeros(4, device='cuda', dtype=torch.float64)
+    f = torch.zeros(4, device='cuda', dtype=torch.float32)
+    L = _lib.load()
+    assert L.oriana_dense_t_times_factor_f32(ptr(t), ptr(f), ptr(t), 1, 1, 129, None) == -2
+    assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, 1, 1, 129, None) == -2
+
+
 @pytest.mark.parametrize('K,m', [(100, 700), (96, 300), (20, 530), (64, 513), (200, 300)])
 def test_deterministic_column_pass(eng, K, m):
     """Debug mode of SURVEY.md section 5 (engine.set_deterministic): the per-gene sums are combined in a fixed order

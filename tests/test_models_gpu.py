@@ -470,8 +470,10 @@ def test_config3_zi_full_size_properties(quirks):
     assert bool((p_d[:8192][nz] == 1.0 - 1e-10).all())
     assert bool((model._D_hat[:8192][nz] == 1.0).all())
     assert bool((p_d[:8192][~nz] < 1.0 - 1e-10).any())
+    # (p_d is evaluated in float64 on access, the sweep's column sums come from its float32 evaluation: the two agree
+    #  far inside the 1e-7 the parity tests allow on pi_d)
     pi_ref = p_d.mean(0)
-    assert float((model.pi_d.tensor - pi_ref).abs().max()) < 1e-12
+    assert float((model.pi_d.tensor - pi_ref).abs().max()) < 2e-8
     for name in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'pi_d'):
         assert torch.isfinite(getattr(model, name).tensor).all(), name
     del model, ct

@@ -314,10 +314,11 @@ int oriana_dense_times_factor(double *out, const float *D, const double *W, int6
  * (nzmask optional as above), colsum[j] += sum_i p_d[i, j] (optional, zero it first), and -- V_next / DV_next both
  * given or both NULL -- DV_next[n, K] += D_hat V_next[m, K] from the tile of D_hat still in registers: with V_next the
  * factor the NEXT sweep's cell update multiplies (zigap.py:116: the V_hat just updated; sparse_zigap.py:138:
- * S_hat * Vprime_hat) that sweep has no pass over D_hat left on the cell side.  DV_next must be zeroed first. */
+ * S_hat * Vprime_hat) that sweep has no pass over D_hat left on the cell side.  DV_next must be zeroed first.
+ * scratch_m: m floats of device scratch (logit(pi_d) in float32). */
 int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d,
                                const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
-                               int64_t n, int64_t m, int64_t K, void *stream);
+                               float *scratch_m, int64_t n, int64_t m, int64_t K, void *stream);
 /* out[m, K] += D_hat^T W[n, K] (zigap.py:124), D_hat streamed once; `out` must be initialised. */
 int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
                                     void *stream);

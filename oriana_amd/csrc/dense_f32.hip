@@ -20,10 +20,13 @@
 // Fragment map of v_mfma_f32_32x32x2_f32: A[m = lane & 31][k = lane >> 5], B[k = lane >> 5][n = lane & 31],
 // D reg v: [m = 8 (v / 4) + 4 (lane >> 5) + v % 4][n = lane & 31].
 #include "common.h"
+// Compile-time ablation switches for the measurements quoted in DESIGN.md (never set in the shipped build):
+// ORIANA_ABL32_NOSTORE / _NOSIG / _NOTRANS / _NOMFMA1 drop one ingredient of k_dropout_sweep.
 
 namespace oriana {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f16v mfma32(float a, float b, f16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -36,7 +39,7 @@ constexpr int TS = 36;            // row stride of the transpose buffer (floats)
 
 // LDS carve-up of k_dropout_sweep (floats)
 struct SweepLds {
-    int us, vt, v2, lg, mk, tb, cs, total;
+    int us, vt, v2, mt, tb, cs, total;
     int v2s;                      // row stride of the [gene][k] image
     __host__ __device__ SweepLds(int KP2, int NT) {
         v2s = NT * 32 + 8;        // 4 rows apart = 32 banks apart: the two lane halves never collide
@@ -44,8 +47,8 @@ struct SweepLds {
         us = o; o += 4 * KP2 * 32;           // [wave][k][32 cells]
         vt = o; o += 2 * KP2 * 32;           // [buf][k][32 genes]
         v2 = o; o += 2 * 32 * v2s;           // [buf][32 genes][k]
-        lg = o; o += 2 * 32;                 // [buf][32 genes] logit(pi_d) with +-inf for the overrides
-        mk = o; o += 2 * 4 * 32;             // [buf][wave][32 genes] non-zero bits of the wave's 32 cells
+        mt = o; o += 2 * 4 * 32 * 2;         // [buf][wave][32 genes] {logit(pi_d) (+-inf: overrides), non-zero bits
+                                             //  of the wave's 32 cells}
         tb = o; o += 4 * 32 * TS;            // [wave][32 cells][32 genes] transpose buffer
         cs = o; o += 2 * 4 * 32;             // [parity][wave][32 genes] column partial sums
         total = o;
@@ -61,7 +64,7 @@ struct SweepLds {
 //   the tile's column sums.
 template <int NT>
 __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float *__restrict__ D_hat, const double *__restrict__ U,
-                                                       const double *__restrict__ V, const double *__restrict__ pi_d,
+                                                       const double *__restrict__ V, const float *__restrict__ lgit,
                                                        const uint32_t *__restrict__ nzmask, double *__restrict__ colsum,
                                                        const double *__restrict__ Vn, double *__restrict__ DV,
                                                        int64_t n, int64_t m, int K, int KP2, int64_t j_per_split) {
@@ -73,7 +76,6 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
     const int64_t je = (jb + j_per_split < m) ? jb + j_per_split : m;
     const int KS = KP2 >> 1;
     float *Us = lds + L.us + w * KP2 * 32;
-    uint32_t *mk = reinterpret_cast<uint32_t *>(lds + L.mk);
     float *T = lds + L.tb + w * 32 * TS;
 
     // the wave's strip of U_hat, [k][cell]
@@ -83,53 +85,66 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
         Us[kk * 32 + cell] = (i < n && kk < K) ? (float)U[i * K + kk] : 0.f;
     }
 
-    // staging of one gene tile, 8 threads per gene: the loads are issued a phase ahead of the LDS stores that consume
-    // them (a store waits for its load: issued back to back they would expose the whole memory latency once per tile)
+    // Staging of one gene tile, 8 threads per gene.  The vector-memory counter of gfx9 retires loads, stores and
+    // atomics in ONE order: a wait for a load also waits for every older store.  So the loads of tile t + 1 are issued
+    // at the top of tile t and consumed (LDS stores) right BEFORE tile t's D_hat stores are issued -- what is older
+    // than them by then (the stores and atomics of tile t - 1) has had a whole tile to drain.
     const int sg = tid >> 3, sk = tid & 7;
     constexpr int NU = NT * 4;                                   // 8 * NU = NT * 32 >= KP2
-    double sreg[NU];
-    float lgreg = 0.f;
+    const bool same_v = (Vn == V);
+    double sreg[NU], nreg[NU];
     uint32_t mkreg = 0;
-    auto stage_load = [&](const double *__restrict__ src, int64_t j0) {
+    // (addresses are clamped into range and the padding is zeroed when the values are consumed: straight-line
+    //  loads, no register is written under a branch)
+    bool sok = false;
+    auto stage_load = [&](int64_t j0) {
         const int64_t j = j0 + sg;
-        const bool jok = j < je;
+        sok = j < je;
+        const int64_t jc = sok ? j : je - 1;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int kk = sk + 8 * u;
-            sreg[u] = (jok && kk < K) ? src[j * K + kk] : 0.0;
+            sreg[u] = V[jc * K + (kk < K ? kk : K - 1)];
+        }
+        if (Vn && !same_v) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int kk = sk + 8 * u;
+                nreg[u] = Vn[jc * K + (kk < K ? kk : K - 1)];
+            }
         }
     };
-    auto stage_store_vt = [&](int buf) {
+    auto stage_store = [&](int buf) {
         float *vt = lds + L.vt + buf * KP2 * 32;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int kk = sk + 8 * u;
-            if (kk < KP2) vt[kk * 32 + sg] = (float)sreg[u];
-        }
-    };
-    auto stage_store_v2 = [&](int buf) {
         float *v2 = lds + L.v2 + buf * 32 * L.v2s;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) v2[sg * L.v2s + sk + 8 * u] = (float)sreg[u];
+        for (int u = 0; u < NU; ++u) {
+            const int kk = sk + 8 * u;
+            const bool ok = sok && kk < K;
+            if (kk < KP2) vt[kk * 32 + sg] = ok ? (float)sreg[u] : 0.f;
+            if (Vn) v2[sg * L.v2s + kk] = ok ? (float)(same_v ? sreg[u] : nreg[u]) : 0.f;
+        }
     };
+    // per gene and wave: {logit(pi_d), the mask word of the wave's 32 cells}; threads 0..127, one (wave, gene) each
+    const int mw = (tid >> 5) & 3;
+    const int64_t mrow = ((int64_t)blockIdx.x * 128 + mw * 32) >> 5;
+    const bool mrow_ok = nzmask && (int64_t)blockIdx.x * 128 + mw * 32 < n;
+    float lgreg = 0.f;
     auto meta_load = [&](int64_t j0) {
-        if (tid < 32) {
-            const int64_t jj = j0 + tid;
-            lgreg = 0.f;
-            if (jj < je) {
-                const double pi = pi_d[jj];
-                lgreg = (pi <= 0.0) ? -INFINITY : (pi >= 1.0) ? INFINITY : (float)logit_f64(pi);
-            }
-        } else if (tid >= 64 && tid < 192) {
-            const int ww = (tid - 64) >> 5, g = tid & 31;
-            const int64_t jj = j0 + g, ir = (int64_t)blockIdx.x * 128 + ww * 32;
-            mkreg = 0;
-            if (nzmask && jj < je && ir < n) mkreg = nzmask[(ir >> 5) * m + jj];
+        if (tid < 128) {
+            const int64_t jj = j0 + (tid & 31);
+            const int64_t jc = jj < je ? jj : je - 1;
+            lgreg = lgit[jc];
+            mkreg = mrow_ok ? nzmask[mrow * m + jc] : 0u;
         }
     };
     auto meta_store = [&](int buf) {
-        if (tid < 32) lds[L.lg + buf * 32 + tid] = lgreg;
-        else if (tid >= 64 && tid < 192) mk[(buf * 4 + ((tid - 64) >> 5)) * 32 + (tid & 31)] = mkreg;
+        if (tid < 128) {
+            float2 pr;
+            pr.x = lgreg;
+            pr.y = __uint_as_float(mkreg);
+            *reinterpret_cast<float2 *>(lds + L.mt + ((buf * 4 + mw) * 32 + (tid & 31)) * 2) = pr;
+        }
     };
 
     f16v dv[NT], dvs[NT];                                       // matrix-core accumulators; their sums every 256 genes
@@ -142,64 +157,110 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
     const bool vec_ok = (m & 3) == 0;
 
     if (jb < je) {
-        stage_load(V, jb);
+        stage_load(jb);
         meta_load(jb);
-        stage_store_vt(0);
+        stage_store(0);
         meta_store(0);
-        if (Vn) { stage_load(Vn, jb); stage_store_v2(0); }
     }
     __syncthreads();
     int buf = 0, par = 0, since_flush = 0;
+    // column sums of the tile before (partials of the 4 waves in LDS): atomics issued AFTER the tile's loads
+    auto colsum_flush = [&](int64_t jt, int parity) {
+        if (colsum && w == 0 && lane < 32 && jt + lane < je) {
+            const float *cs = lds + L.cs + parity * 4 * 32 + lane;
+            atomicAdd(&colsum[jt + lane], (double)cs[0] + (double)cs[32] + (double)cs[64] + (double)cs[96]);
+        }
+    };
     for (int64_t j0 = jb; j0 < je; j0 += 32) {
         const bool more = j0 + 32 < je;
-        if (more) { stage_load(V, j0 + 32); meta_load(j0 + 32); }
-        // ---- Lambda^T = V U^T
+        { const int64_t jn = more ? j0 + 32 : j0; stage_load(jn); meta_load(jn); }   // (the last tile again: unused)
+        if (j0 > jb) colsum_flush(j0 - 32, par ^ 1);
+        // ---- Lambda^T = V U^T: four steps per turn, the operands of the next turn requested before the matrix
+        // instructions of this one (an LDS round trip is longer than one 16-pass instruction)
         const float *vt = lds + L.vt + buf * KP2 * 32;
         f16v l0;
 #pragma unroll
         for (int v = 0; v < 16; ++v) l0[v] = 0.f;
-        for (int s = 0; s < KS; ++s) l0 = mfma32(vt[(2 * s + h) * 32 + c], Us[(2 * s + h) * 32 + c], l0);
-        if (more) {
-            stage_store_vt(buf ^ 1);
-            meta_store(buf ^ 1);
-            if (Vn) stage_load(Vn, j0 + 32);
+        {
+            const float *pa = vt + h * 32 + c, *pb = Us + h * 32 + c;
+            float a[4], b[4], an[4], bn[4];
+            int s = 0;
+            if (KS >= 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = pa[64 * u]; b[u] = pb[64 * u]; }
+                for (; s + 8 <= KS; s += 4) {
+                    pa += 256; pb += 256;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { an[u] = pa[64 * u]; bn[u] = pb[64 * u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) l0 = mfma32(a[u], b[u], l0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+                }
+                pa += 256; pb += 256;
+                // the remainder's operands, then the last full turn
+                const int rem = KS - s - 4;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { const int o = (u < rem) ? 64 * u : 0; an[u] = pa[o]; bn[u] = pb[o]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) l0 = mfma32(a[u], b[u], l0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (u < rem) l0 = mfma32(an[u], bn[u], l0);
+            } else {
+                for (; s < KS; ++s) l0 = mfma32(pa[64 * s], pb[64 * s], l0);
+            }
         }
         // ---- sigmoid, overrides
-        const float *lgs = lds + L.lg + buf * 32;
-        const uint32_t *mks = mk + (buf * 4 + w) * 32;
+        const int jrem = (je - j0 < 32) ? (int)(je - j0) : 32;
+        const float2 *mts = reinterpret_cast<const float2 *>(lds + L.mt) + (buf * 4 + w) * 32;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int g = acc_row(v, h);
-            const float lgv = lgs[g];
-            const uint32_t word = mks[g];
+            const float2 mt = mts[acc_row(v, h)];
             if ((v & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // four entries at a time: bounded register use
-            const float x = lgv - l0[v];
+            const float x = mt.x - l0[v];
+#ifdef ORIANA_ABL32_NOSIG
+            float p = x;
+#else
             float p = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-            if (lgv == -INFINITY) p = 1e-10f;                    // pi_d <= 0                         zigap.py:133
-            if ((word >> c) & 1u) p = 1.0f;                      // X != 0: f32(1 - 1e-10) == 1       zigap.py:135
-            if (!rowok || j0 + g >= je) p = 0.f;                 // padding never reaches a sum
+#endif
+            if (mt.x == -INFINITY) p = 1e-10f;                   // pi_d <= 0                         zigap.py:133
+            if ((__float_as_uint(mt.y) >> c) & 1u) p = 1.0f;     // X != 0: f32(1 - 1e-10) == 1       zigap.py:135
             l0[v] = p;
-            T[c * TS + g] = p;
         }
+        if (!(jrem == 32 && i0w + 32 <= n)) {                    // (uniform) padding never reaches a sum
+#pragma unroll
+            for (int v = 0; v < 16; ++v) if (!rowok || acc_row(v, h) >= jrem) l0[v] = 0.f;
+        }
+#ifndef ORIANA_ABL32_NOTRANS
+#pragma unroll
+        for (int v = 0; v < 16; ++v) T[c * TS + acc_row(v, h)] = l0[v];
+#endif
         __builtin_amdgcn_wave_barrier();
+        stage_store(buf ^ 1);
+        meta_store(buf ^ 1);
         // ---- D_hat rows out, column sums of the tile
         {
             const int gq = (lane & 7) * 4;
-            float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool full = vec_ok && jrem == 32;              // uniform: whole 16-byte pieces
+            f4v csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = (lane >> 3) + 8 * q;
-                const float4 t = *reinterpret_cast<const float4 *>(T + r * TS + gq);
-                csum.x += t.x; csum.y += t.y; csum.z += t.z; csum.w += t.w;
-                const int64_t i = i0w + r, j = j0 + gq;
+                const f4v t = *reinterpret_cast<const f4v *>(T + r * TS + gq);
+                csum += t;
+                const int64_t i = i0w + r;
+#ifdef ORIANA_ABL32_NOSTORE
+                if (D_hat && i < n && t.x == 12345.678f) {
+#else
                 if (D_hat && i < n) {
-                    float *dst = D_hat + i * m + j;
-                    if (vec_ok && j + 4 <= je) *reinterpret_cast<float4 *>(dst) = t;
+#endif
+                    float *dst = D_hat + i * m + j0 + gq;
+                    if (full) *reinterpret_cast<f4v *>(dst) = t;
                     else {
-                        if (j + 0 < je) dst[0] = t.x;
-                        if (j + 1 < je) dst[1] = t.y;
-                        if (j + 2 < je) dst[2] = t.z;
-                        if (j + 3 < je) dst[3] = t.w;
+                        if (gq + 0 < jrem) dst[0] = t.x;
+                        if (gq + 1 < jrem) dst[1] = t.y;
+                        if (gq + 2 < jrem) dst[2] = t.z;
+                        if (gq + 3 < jrem) dst[3] = t.w;
                     }
                 }
             }
@@ -209,7 +270,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
                     csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
                     csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
                 }
-                if (lane < 8) *reinterpret_cast<float4 *>(lds + L.cs + (par * 4 + w) * 32 + gq) = csum;
+                if (lane < 8) *reinterpret_cast<f4v *>(lds + L.cs + (par * 4 + w) * 32 + gq) = csum;
             }
         }
         // ---- DV += D V_next
@@ -228,16 +289,12 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
 #pragma unroll
                     for (int v = 0; v < 16; ++v) { dvs[nt][v] += dv[nt][v]; dv[nt][v] = 0.f; }
             }
-            if (more) stage_store_v2(buf ^ 1);
         }
         __syncthreads();
-        if (colsum && w == 0 && lane < 32 && j0 + lane < je) {
-            const float *cs = lds + L.cs + par * 4 * 32 + lane;
-            atomicAdd(&colsum[j0 + lane], (double)cs[0] + (double)cs[32] + (double)cs[64] + (double)cs[96]);
-        }
         buf ^= 1;
         par ^= 1;
     }
+    if (jb < je) colsum_flush(jb + ((je - jb - 1) / 32) * 32, par ^ 1);
     if (Vn && DV) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -314,37 +371,41 @@ __global__ __launch_bounds__(256) void k_dt_times_factor_f32(double *__restrict_
         }
     };
 
-    Frag cur[PF], nxt[PF];
-    constexpr int NG = RC / (2 * PF);                            // groups per chunk
+    // ring of RING row pairs: the slot a matrix instruction has just consumed is refilled with the pair RING steps ahead
+    constexpr int RING = 2 * PF;
+    constexpr int NG = RC / (2 * PF);                            // staging groups (PF row pairs) per chunk
+    static_assert(RC / 2 % RING == 0, "a chunk is a whole number of ring turns");
+    Frag ring[RING];
     if (ib < ie) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) { stage_load(ib, g); stage_store(0, g); }
 #pragma unroll
-        for (int p = 0; p < PF; ++p) load_d(cur[p], ib + 2 * p + h);
+        for (int p = 0; p < RING; ++p) load_d(ring[p], ib + 2 * p + h);
     }
     __syncthreads();
     int buf = 0, chunks = 0;
     for (int64_t i0 = ib; i0 < ie; i0 += RC) {
         const bool more = i0 + RC < ie;
 #pragma unroll 1
-        for (int g = 0; g < NG; ++g) {
-            const int s0 = g * PF;
+        for (int t = 0; t < RC / 2 / RING; ++t) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) load_d(nxt[p], i0 + 2 * (s0 + PF + p) + h);
-            if (more) stage_load(i0 + RC, g);
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * t + gg, s0 = g * PF;
+                if (more) stage_load(i0 + RC, g);
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const float *wrow = &Ws[buf][(2 * (s0 + p) + h) * WS + c];
+                for (int p = 0; p < PF; ++p) {
+                    const float *wrow = &Ws[buf][(2 * (s0 + p) + h) * WS + c];
+                    Frag &f = ring[gg * PF + p];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float b = wrow[nt * 32];
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float b = wrow[nt * 32];
 #pragma unroll
-                    for (int q = 0; q < GQ; ++q) acc[q][nt] = mfma32(cur[p].d[q], b, acc[q][nt]);
+                        for (int q = 0; q < GQ; ++q) acc[q][nt] = mfma32(f.d[q], b, acc[q][nt]);
+                    }
+                    load_d(f, i0 + 2 * (s0 + p + RING) + h);
                 }
+                if (more) stage_store(buf ^ 1, g);
             }
-            if (more) stage_store(buf ^ 1, g);
-#pragma unroll
-            for (int p = 0; p < PF; ++p) cur[p] = nxt[p];
         }
         if (++chunks == 256 / RC) {                              // 256 rows: leave the matrix core
             chunks = 0;
@@ -370,8 +431,17 @@ __global__ __launch_bounds__(256) void k_dt_times_factor_f32(double *__restrict_
             }
 }
 
+// logit(pi_d) in float32, with the overrides of zigap.py:133-134 encoded as -inf (pi_d <= 0: p_d = 1e-10) and +inf
+// (pi_d >= 1: p_d = 1 - 1e-10, 1 in float32)
+__global__ void k_logit_f32(float *__restrict__ lg, const double *__restrict__ pi_d, int64_t m) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double pi = pi_d[j];
+    lg[j] = (pi <= 0.0) ? -INFINITY : (pi >= 1.0) ? INFINITY : (float)logit_f64(pi);
+}
+
 template <int NT>
-static int launch_sweep(float *D_hat, const double *U, const double *V, const double *pi_d, const uint32_t *nzmask,
+static int launch_sweep(float *D_hat, const double *U, const double *V, const float *pi_d, const uint32_t *nzmask,
                         double *colsum, const double *Vn, double *DV, int64_t n, int64_t m, int K, hipStream_t st) {
     const int KP2 = (K + 1) & ~1;
     const SweepLds L(KP2, NT);
@@ -415,14 +485,16 @@ static int launch_dt(double *out, const float *D, const double *W, int64_t n, in
 
 using namespace oriana;
 
-extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d,
+extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d64,
                                           const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
-                                          int64_t n, int64_t m, int64_t K, void *stream) {
+                                          float *scratch_m, int64_t n, int64_t m, int64_t K, void *stream) {
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (K > 128) return ORIANA_EKRANGE;
     if (n == 0 || m == 0) return 0;
-    if (!D_hat || !U || !V || !pi_d || ((V_next == nullptr) != (DV_next == nullptr))) return ORIANA_EINVAL;
+    if (!D_hat || !U || !V || !pi_d64 || !scratch_m || ((V_next == nullptr) != (DV_next == nullptr))) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch_m, pi_d64, m);
+    const float *pi_d = scratch_m;
     int rc;
     switch ((int)((K + 31) / 32)) {
         case 1: rc = launch_sweep<1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;

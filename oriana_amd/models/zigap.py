@@ -48,6 +48,7 @@ class _ZIMixin:
         # valid while (D_hat, V_hat, S_hat) are the tensors it was formed from: _ver counts their writes
         self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
         self._DV_next = None
+        self._lg_scratch = torch.zeros(max(m, 1), dtype=torch.float32, device=dev)
 
     @property
     def D_hat(self):
@@ -122,7 +123,8 @@ class _ZIMixin:
                     DV = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
                     V_next = V_next.contiguous()
                 call('oriana_dropout_sweep_fused', ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
-                     ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), self.n, self.m, self.k, stream_ptr())
+                     ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self.n, self.m,
+                     self.k, stream_ptr())
             else:
                 DV = None
                 call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),

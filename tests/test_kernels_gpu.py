@@ -543,8 +543,9 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next):
     D1 = torch.full((n, m), -7.0, dtype=torch.float32, device='cuda')
     cs1 = torch.zeros(m, dtype=torch.float64, device='cuda')
     DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
+    lgs = torch.zeros(m, dtype=torch.float32, device='cuda')
     call('oriana_dropout_sweep_fused', ptr(D1), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs1),
-         ptr(Vn) if with_next else None, ptr(DV) if with_next else None, n, m, K, stream_ptr())
+         ptr(Vn) if with_next else None, ptr(DV) if with_next else None, ptr(lgs), n, m, K, stream_ptr())
     D2 = torch.empty_like(D1)
     cs2 = torch.zeros_like(cs1)
     call('oriana_dropout_update_fused', None, ptr(D2), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs2), n, m, K, stream_ptr())
@@ -577,7 +578,7 @@ def test_f32_dense_entries_reject_large_K():
     f = torch.zeros(4, device='cuda', dtype=torch.float32)
     L = _lib.load()
     assert L.oriana_dense_t_times_factor_f32(ptr(t), ptr(f), ptr(t), 1, 1, 129, None) == -2
-    assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, 1, 1, 129, None) == -2
+    assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, ptr(f), 1, 1, 129, None) == -2
 
 
 @pytest.mark.parametrize('K,m', [(100, 700), (96, 300), (20, 530), (64, 513), (200, 300)])

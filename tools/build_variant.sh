@@ -5,7 +5,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=/tmp/oriana_variants/$1
 mkdir -p $O
-for f in pack passes updates dense dense_mfma metrics stateless; do
+for f in pack passes updates dense dense_mfma dense_f32 metrics stateless; do
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $2 -c $R/oriana_amd/csrc/$f.hip -o $O/$f.o &
 done
 wait

@@ -20,6 +20,7 @@
 // Fragment map of v_mfma_f32_32x32x2_f32: A[m = lane & 31][k = lane >> 5], B[k = lane >> 5][n = lane & 31],
 // D reg v: [m = 8 (v / 4) + 4 (lane >> 5) + v % 4][n = lane & 31].
 #include "common.h"
+#include <type_traits>
 // Compile-time ablation switches for the measurements quoted in DESIGN.md (never set in the shipped build):
 // ORIANA_ABL32_NOSTORE / _NOSIG / _NOTRANS / _NOMFMA1 drop one ingredient of k_dropout_sweep.
 
@@ -31,6 +32,10 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16v mfma32(float a, float b, f16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// Scheduling fence for vector-memory instructions only (everything else may cross): keeps a prefetch where it was
+// written -- left alone, the scheduler sinks such loads down to their first use, i.e. turns them into plain loads.
+#define ORIANA_VMEM_FENCE() __builtin_amdgcn_sched_barrier(0x38F)
 
 // row of the accumulator register v in lane half h
 __device__ __forceinline__ int acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
         const bool more = j0 + 32 < je;
         { const int64_t jn = more ? j0 + 32 : j0; stage_load(jn); meta_load(jn); }   // (the last tile again: unused)
         if (j0 > jb) colsum_flush(j0 - 32, par ^ 1);
+        ORIANA_VMEM_FENCE();
         // ---- Lambda^T = V U^T: four steps per turn, the operands of the next turn requested before the matrix
         // instructions of this one (an LDS round trip is longer than one 16-pass instruction)
         const float *vt = lds + L.vt + buf * KP2 * 32;
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
         __builtin_amdgcn_wave_barrier();
         stage_store(buf ^ 1);
         meta_store(buf ^ 1);
+        ORIANA_VMEM_FENCE();
         // ---- D_hat rows out, column sums of the tile
         {
             const int gq = (lane & 7) * 4;
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
 // load per row) and NT * 32 factors; the 4 waves of a group share the rows [ib, ie) and the W chunks staged in LDS.
 // A = D^T (m index = gene slot), B = W chunk; per row pair GQ * NT matrix instructions.
 template <int NT, int GQ>
-__global__ __launch_bounds__(256) void k_dt_times_factor_f32(double *__restrict__ out, const float *__restrict__ D,
+__global__ __launch_bounds__(256, (NT < 4) ? 2 : 1) void k_dt_times_factor_f32(double *__restrict__ out, const float *__restrict__ D,
                                                              const double *__restrict__ W, int64_t n, int64_t m, int K,
                                                              int64_t i_per_split) {
     constexpr int WS = (NT & 1) ? NT * 32 : NT * 32 + 32;       // rows one apart = 32 banks apart
@@ -338,19 +345,24 @@ __global__ __launch_bounds__(256) void k_dt_times_factor_f32(double *__restrict_
     constexpr int NW = NT * 2;                                   // 16 * NW = NT * 32 factors
     const int sr = tid >> 4, sk = tid & 15;
     double wreg[NW];
+    // (clamped addresses, padding zeroed when the values are stored: straight-line loads that the compiler leaves where
+    //  they are issued -- a load under a branch drags its conversion, and with it the wait, up to the load)
+    bool wok = false;
     auto stage_load = [&](int64_t i0, int grp) {
         const int64_t i = i0 + grp * 2 * PF + sr;
-        const bool iok = i < ie;
+        wok = i < ie;
+        const double *src = W + (wok ? i : ie - 1) * K;
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
             const int kk = sk + 16 * u;
-            wreg[u] = (iok && kk < K) ? W[i * K + kk] : 0.0;
+            wreg[u] = src[kk < K ? kk : K - 1];
         }
     };
     auto stage_store = [&](int buf, int grp) {
         const int r = grp * 2 * PF + sr;
 #pragma unroll
-        for (int u = 0; u < NW; ++u) Ws[buf][r * WS + sk + 16 * u] = (float)wreg[u];
+        for (int u = 0; u < NW; ++u)                             // (a product, not a select: the load stays unconditional)
+            Ws[buf][r * WS + sk + 16 * u] = (float)wreg[u] * ((wok && sk + 16 * u < K) ? 1.f : 0.f);
     };
     struct Frag { float d[GQ]; };
     auto load_d = [&](Frag &f, int64_t i) {
@@ -384,29 +396,63 @@ __global__ __launch_bounds__(256) void k_dt_times_factor_f32(double *__restrict_
     }
     __syncthreads();
     int buf = 0, chunks = 0;
-    for (int64_t i0 = ib; i0 < ie; i0 += RC) {
-        const bool more = i0 + RC < ie;
+    // interior of the matrix (every row the ring will ask for exists, the wave's genes are whole vectors): one
+    // vector load from a running pointer per row pair, nothing else
+    typedef float dvec __attribute__((ext_vector_type(GQ == 1 ? 2 : GQ)));   // (GQ == 1 takes the scalar branch)
+    const bool wave_fast = vec_ok && jw + 32 * GQ <= m;
+    // One step = one row pair: the B operands of the NEXT step are requested, the matrix instructions of this step
+    // issued, the ring slot refilled -- and a full scheduling fence: the order below is the schedule (left to itself
+    // the scheduler sinks the prefetches down to their uses, i.e. exposes every latency they were written to hide).
+    auto chunk = [&](auto fast_tag, int64_t i0, bool more) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const float *dp = D + (i0 + 2 * RING + h) * m + j;       // (dereferenced on the fast path only)
+        const int64_t dstep = 2 * m;
+        float bc[NT], bn[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bc[nt] = Ws[buf][h * WS + c + nt * 32];
 #pragma unroll 1
         for (int t = 0; t < RC / 2 / RING; ++t) {
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
                 const int g = 2 * t + gg, s0 = g * PF;
-                if (more) stage_load(i0 + RC, g);
+                stage_load(more ? i0 + RC : i0, g);              // (unconditional; the last chunk is staged again, unread)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < PF; ++p) {
-                    const float *wrow = &Ws[buf][(2 * (s0 + p) + h) * WS + c];
+                    const int sn = (s0 + p + 1 < RC / 2) ? s0 + p + 1 : RC / 2 - 1;
+                    const float *wrow = &Ws[buf][(2 * sn + h) * WS + c];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = wrow[nt * 32];
+                    __builtin_amdgcn_sched_barrier(0);
                     Frag &f = ring[gg * PF + p];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const float b = wrow[nt * 32];
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int q = 0; q < GQ; ++q) acc[q][nt] = mfma32(f.d[q], b, acc[q][nt]);
+                        for (int q = 0; q < GQ; ++q) acc[q][nt] = mfma32(f.d[q], bc[nt], acc[q][nt]);
+                    if (FAST) {
+                        if (GQ == 1) f.d[0] = *dp;
+                        else {
+                            const dvec tv = *reinterpret_cast<const dvec *>(dp);
+#pragma unroll
+                            for (int q = 0; q < GQ; ++q) f.d[q] = tv[q];
+                        }
+                        dp += dstep;
+                    } else {
+                        load_d(f, i0 + 2 * (s0 + p + RING) + h);
                     }
-                    load_d(f, i0 + 2 * (s0 + p + RING) + h);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (more) stage_store(buf ^ 1, g);
+                stage_store(buf ^ 1, g);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+    for (int64_t i0 = ib; i0 < ie; i0 += RC) {
+        const bool more = i0 + RC < ie;
+        if (wave_fast && i0 + RC + 2 * RING <= ie) chunk(std::true_type{}, i0, more);
+        else chunk(std::false_type{}, i0, more);
         if (++chunks == 256 / RC) {                              // 256 rows: leave the matrix core
             chunks = 0;
 #pragma unroll
@@ -431,6 +477,25 @@ __global__ __launch_bounds__(256) void k_dt_times_factor_f32(double *__restrict_
             }
 }
 
+// Number of ranges to cut the reduction (or gene) axis into, given `blocks` work-groups along the other axis: the
+// grid runs in rounds of 512 resident work-groups (2 per CU), and a last round that is nearly empty costs as much as a
+// full one -- 1580 groups take 4 rounds at 77 %.  Among 4 to 12 rounds' worth, the count that leaves the last round
+// fullest (fewer ranges on ties: each one ends in a set of float64 atomics).
+static int64_t pick_splits(int64_t blocks, int64_t max_splits) {
+    const int64_t slots = 512;
+    int64_t best = 1;
+    double best_eff = 0.0;
+    for (int64_t sp = 1; sp <= max_splits && sp <= 4096; ++sp) {
+        const int64_t groups = blocks * sp;
+        if (groups > 12 * slots && sp > 1) break;
+        const int64_t rounds = (groups + slots - 1) / slots;
+        double eff = (double)groups / (double)(rounds * slots);
+        if (groups < 4 * slots) eff *= 0.5 + 0.125 * (double)groups / (double)slots;   // too few to hide the tails
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    return best;
+}
+
 // logit(pi_d) in float32, with the overrides of zigap.py:133-134 encoded as -inf (pi_d <= 0: p_d = 1e-10) and +inf
 // (pi_d >= 1: p_d = 1 - 1e-10, 1 in float32)
 __global__ void k_logit_f32(float *__restrict__ lg, const double *__restrict__ pi_d, int64_t m) {
@@ -447,14 +512,11 @@ static int launch_sweep(float *D_hat, const double *U, const double *V, const fl
     const SweepLds L(KP2, NT);
     const size_t lds = (size_t)L.total * sizeof(float);
     const int64_t rb = (n + 127) / 128;
-    // gene ranges: multiples of 256 (the float64 hand-over), enough groups to fill the chip a few times over
-    int64_t splits = (2048 + rb - 1) / rb;
-    const int64_t max_splits = (m + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int64_t jps = (m + splits - 1) / splits;
-    jps = (jps + 255) / 256 * 256;
-    splits = (m + jps - 1) / jps;
+    // gene ranges: whole tiles of 32, as many per row block as fills the chip's work-group slots evenly
+    const int64_t splits0 = pick_splits(rb, (m + 255) / 256);
+    int64_t jps = (m + splits0 - 1) / splits0;
+    jps = (jps + 31) / 32 * 32;
+    const int64_t splits = (m + jps - 1) / jps;
     if (splits > 65535 || rb > 0x7fffffffLL) return ORIANA_EINVAL;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_dropout_sweep<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -468,13 +530,10 @@ static int launch_sweep(float *D_hat, const double *U, const double *V, const fl
 template <int NT, int GQ>
 static int launch_dt(double *out, const float *D, const double *W, int64_t n, int64_t m, int K, hipStream_t st) {
     const int64_t jb = (m + 128 * GQ - 1) / (128 * GQ);
-    int64_t splits = (1536 + jb - 1) / jb;
-    const int64_t max_splits = (n + 511) / 512;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int64_t ips = (n + splits - 1) / splits;
-    ips = (ips + 511) / 512 * 512;
-    splits = (n + ips - 1) / ips;
+    const int64_t splits0 = pick_splits(jb, (n + 255) / 256);
+    int64_t ips = (n + splits0 - 1) / splits0;
+    ips = (ips + 63) / 64 * 64;                                  // whole staged chunks
+    const int64_t splits = (n + ips - 1) / ips;
     if (splits > 65535 || jb > 0x7fffffffLL) return ORIANA_EINVAL;
     hipLaunchKernelGGL((k_dt_times_factor_f32<NT, GQ>), dim3((unsigned)jb, (unsigned)splits), dim3(256), 0, st, out, D, W,
                        n, m, K, ips);

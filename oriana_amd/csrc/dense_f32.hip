@@ -44,7 +44,7 @@ constexpr int TS = 36;            // row stride of the transpose buffer (floats)
 
 // LDS carve-up of k_dropout_sweep (floats)
 struct SweepLds {
-    int us, vt, v2, mt, tb, cs, total;
+    int us, vt, v2, mt, tb, cs, dm, total;
     int v2s;                      // row stride of the [gene][k] image
     __host__ __device__ SweepLds(int KP2, int NT) {
         v2s = NT * 32 + 8;        // 4 rows apart = 32 banks apart: the two lane halves never collide
@@ -56,6 +56,7 @@ struct SweepLds {
                                              //  of the wave's 32 cells}
         tb = o; o += 4 * 32 * TS;            // [wave][32 cells][32 genes] transpose buffer
         cs = o; o += 2 * 4 * 32;             // [parity][wave][32 genes] column partial sums
+        dm = o; o += 32;                     // where the staging writes of k >= KP2 land (no branch per element)
         total = o;
     }
 };
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
         for (int u = 0; u < NU; ++u) {
             const int kk = sk + 8 * u;
             const bool ok = sok && kk < K;
-            if (kk < KP2) vt[kk * 32 + sg] = ok ? (float)sreg[u] : 0.f;
+            (kk < KP2 ? vt + kk * 32 : lds + L.dm)[sg] = ok ? (float)sreg[u] : 0.f;
             if (Vn) v2[sg * L.v2s + kk] = ok ? (float)(same_v ? sreg[u] : nreg[u]) : 0.f;
         }
     };
@@ -282,12 +283,21 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
         }
         // ---- DV += D V_next
         if (Vn) {
-            const float *v2 = lds + L.v2 + buf * 32 * L.v2s;
+            const float *v2 = lds + L.v2 + buf * 32 * L.v2s + c;
+            float bc[NT], bn[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bc[nt] = v2[acc_row(0, h) * L.v2s + nt * 32];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int g = acc_row(v, h);
+                const int gn = acc_row(v < 15 ? v + 1 : 15, h);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) dv[nt] = mfma32(l0[v], v2[g * L.v2s + nt * 32 + c], dv[nt]);
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = v2[gn * L.v2s + nt * 32];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) dv[nt] = mfma32(l0[v], bc[nt], dv[nt]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (++since_flush == 8) {                            // 256 genes: leave the matrix core
                 since_flush = 0;

@@ -38,6 +38,15 @@ def build(force=False):
     return so
 
 
+def build_omp(force=False):
+    """Compile oracle/zq_kernels_omp.c -> oracle/liboracle_omp.so (the labelled all-cores variant of bench.py)."""
+    so = os.path.join(_HERE, 'liboracle_omp.so')
+    src = os.path.join(_HERE, 'zq_kernels_omp.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s', 'liboracle_omp.so'])
+    return so
+
+
 def _lib():
     global _LIB
     if _LIB is None:
@@ -61,11 +70,7 @@ def zq_gap_omp(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X, nthreads):
     thread, gap.py:67) -- a second, labelled CPU figure for bench.py.  Raises if the OpenMP build is unavailable."""
     global _LIB_OMP
     if _LIB_OMP is None:
-        so = os.path.join(_HERE, 'liboracle_omp.so')
-        src = os.path.join(_HERE, 'zq_kernels_omp.c')
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            subprocess.check_call(['make', '-C', _HERE, '-s', 'liboracle_omp.so'])
-        _LIB_OMP = ctypes.CDLL(so)
+        _LIB_OMP = ctypes.CDLL(build_omp())
         fp = ctypes.POINTER(ctypes.c_float)
         _LIB_OMP.zq_gap_omp.argtypes = [fp] * 5 + [ctypes.c_int64] * 3 + [ctypes.c_int]
         _LIB_OMP.zq_gap_omp.restype = ctypes.c_int

@@ -1508,7 +1508,7 @@ extern "C" int64_t oriana_kpad(int64_t K) {
     return 4 * c.G * c.T4 + c.G * c.TAIL;
 }
 
-extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.3"; }
+extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.4"; }
 
 extern "C" int64_t oriana_col_block_tiles(int64_t K) {
     KCfg c;

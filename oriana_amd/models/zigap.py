@@ -48,6 +48,7 @@ class _ZIMixin:
         # valid while (D_hat, V_hat, S_hat) are the tensors it was formed from: _ver counts their writes
         self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
         self._DV_next = None
+        self.n_kept_products = 0          # sweeps whose D_hat V came from the previous sweep's D update
         self._lg_scratch = torch.zeros(max(m, 1), dtype=torch.float32, device=dev)
 
     @property
@@ -89,6 +90,7 @@ class _ZIMixin:
         kept = self._DV_next
         self._DV_next = None
         if kept is not None and kept[1] == self._ver:
+            self.n_kept_products += 1
             return kept[0]
         out = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
         with engine._span(self._ws, 'DV'):

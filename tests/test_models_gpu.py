@@ -83,6 +83,36 @@ def test_trajectory(path):
     assert_state_close(M.state(), state_of(g, 's10'), rtol=2e-2, keys=loose, what='s10 free-running')
 
 
+@pytest.mark.parametrize('path', [f for f in _files() if 'zigap' in os.path.basename(f)], ids=os.path.basename)
+def test_zi_sweeps_float32_matrix_path_against_float64(path):
+    """The ZI sweep on the float32 matrix cores (D update fused with the next sweep's D_hat V, D_hat^T U streamed once;
+    csrc/dense_f32.hip) against the float64 kernels of round 1 (ORIANA_ZI_EXACT=1), free-running from the reference's
+    start: the single-sweep goldens reload the state before every sweep and never reach the kept product."""
+    g = load_golden(path)
+    fast, exact = _make(g), _make(g)
+    exact._fast_dense = False
+    assert fast._fast_dense
+    for sweep in range(1, 4):
+        fast.step(); exact.step()
+        assert exact.n_kept_products == 0 and fast.n_kept_products == sweep - 1     # first sweep: nothing to keep yet
+        sf, se = fast.state(), exact.state()
+        for k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'U_hat', 'V_hat'):
+            # measured <= 3e-7 per sweep; free-running, so the bound grows with the sweep
+            assert err_colrel(sf[k], se[k]) < 1e-6 * sweep, (sweep, k, err_colrel(sf[k], se[k]))
+        assert float(np.max(np.abs(sf['p_d'] - se['p_d']))) < 2e-6 * sweep
+        assert float(np.max(np.abs(sf['pi_d'] - se['pi_d']))) < 1e-7 * sweep
+        assert float(np.max(np.abs(fast.D_hat - exact.D_hat))) < 1e-6 * sweep
+    # and both stay on the reference's trajectory (same bound as test_trajectory)
+    assert_state_close(fast.state(), state_of(g, 's3'), rtol=1e-3, keys=['a1', 'a2', 'b1', 'b2', 'U_hat', 'V_hat'], what='s3')
+    # a state written from outside drops the kept product: the next sweep takes the float64 product again
+    kept = fast.n_kept_products
+    fast.load_state(state_of(g, 's1'))
+    fast.step()
+    assert fast.n_kept_products == kept
+    assert_state_close(fast.state(), state_of(g, 's2'), what='s1->s2 after load_state',
+                       keys=['a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'p_d', 'pi_d', 'U_hat', 'V_hat'])
+
+
 def test_factors_and_attributes():
     g = load_golden(golden_files('gap_c1_rand.npz')[0])
     M = _make(g)

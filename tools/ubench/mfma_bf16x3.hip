@@ -1,0 +1,176 @@
+// float32 products on the bf16 matrix cores of gfx950: x = hi + mid + lo (three bf16, 24 bits), six of the nine
+// cross products (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi) on v_mfma_f32_32x32x16_bf16, float32 accumulation.
+// (1) error of a long positive sum against float64, next to the float32 matrix instruction; (2) rate; (3) does VALU
+// work overlap with these matrix instructions (it does not with v_mfma_f32_32x32x2_f32, mfma_valu_overlap.hip)?
+// Fragment map assumed (checked by (1)): A[m = lane & 31][k = 8 (lane >> 5) + e], B[k = 8 (lane >> 5) + e][n = lane & 31],
+// e = 0..7 the eight bf16 of the lane; D as for the float32 32x32 instructions.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
+    const unsigned xb = __float_as_uint(x);
+    const float fh = __uint_as_float(xb & 0xFFFF0000u);          // truncation: the remainders are exact
+    const float r1 = x - fh;
+    const float fm = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    const float r2 = r1 - fm;
+    h = (unsigned short)(xb >> 16);
+    m = (unsigned short)(__float_as_uint(r1) >> 16);
+    l = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+__global__ void k_chain(float *C, const float *A, const float *B, int S) {      // A [32][16 S], B [16 S][32], one wave
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    f16v acc = {0};
+    for (int s = 0; s < S; ++s) {
+        s8 a[3], b[3];
+        for (int e = 0; e < 8; ++e) {
+            unsigned short x0, x1, x2;
+            split3(A[r * 16 * S + 16 * s + 8 * h + e], x0, x1, x2);
+            a[0][e] = (short)x0; a[1][e] = (short)x1; a[2][e] = (short)x2;
+            split3(B[(16 * s + 8 * h + e) * 32 + r], x0, x1, x2);
+            b[0][e] = (short)x0; b[1][e] = (short)x1; b[2][e] = (short)x2;
+        }
+        // small terms first
+        const int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+        for (int t = 0; t < 6; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[ia[t]]), __builtin_bit_cast(bf8, b[ib[t]]), acc, 0, 0, 0);
+    }
+    for (int v = 0; v < 16; ++v) C[(8 * (v / 4) + 4 * h + v % 4) * 32 + r] = acc[v];
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_rate(float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16v a0 = {0}, a1 = a0;
+    s8 x, y;
+    for (int e = 0; e < 8; ++e) { x[e] = (short)(0x3f80 + lane); y[e] = (short)(0x3f00 + e); }
+    f2 v0 = {1.f + lane, 2.f}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
+    const f2 m = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), a1, 0, 0, 0);
+            else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), a0, 0, 0, 0);
+            if (NV) {
+#pragma unroll
+                for (int q = 0; q < NV / 8; ++q) {
+                    v0 = __builtin_elementwise_fma(v0, m, c); v1 = __builtin_elementwise_fma(v1, m, c);
+                    v2 = __builtin_elementwise_fma(v2, m, c); v3 = __builtin_elementwise_fma(v3, m, c);
+                    v4 = __builtin_elementwise_fma(v4, m, c); v5 = __builtin_elementwise_fma(v5, m, c);
+                    v6 = __builtin_elementwise_fma(v6, m, c); v7 = __builtin_elementwise_fma(v7, m, c);
+                }
+            }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[1] + v0.x + v1.x + v2.y + v3.x + v4.x + v5.y + v6.x + v7.x;
+}
+// KIND 0: v_fma_f32, 1: integer (v_and / v_sub_f32 / v_perm: the split's own mix); MF: with one matrix instruction per 8
+template <int KIND, int MF>
+__global__ __launch_bounds__(512) void k_mix(float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16v a0 = {0}, a1 = a0;
+    s8 x, y;
+    for (int e = 0; e < 8; ++e) { x[e] = (short)(0x3f80 + lane); y[e] = (short)(0x3f00 + e); }
+    float v[8];
+    for (int e = 0; e < 8; ++e) v[e] = 1.f + lane + e;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (MF) {
+                if (u & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), a1, 0, 0, 0);
+                else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, x), __builtin_bit_cast(bf8, y), a0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (KIND == 0) v[e] = __builtin_fmaf(v[e], 1.0001f, 0.5f);
+                else {
+                    const unsigned b = __float_as_uint(v[e]);
+                    const float hi = __uint_as_float(b & 0xFFFF0000u);
+                    v[e] = (v[e] - hi) + __uint_as_float(__builtin_amdgcn_perm(b, b ^ 0x5a5a5a5au, 0x07060302u));
+                }
+            }
+        }
+    }
+    float sum = a0[0] + a1[1];
+    for (int e = 0; e < 8; ++e) sum += v[e];
+    out[blockIdx.x * 512 + threadIdx.x] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_valu(float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f2 v0 = {1.f + lane, 2.f}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
+    const f2 m = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v0 = __builtin_elementwise_fma(v0, m, c); v1 = __builtin_elementwise_fma(v1, m, c);
+            v2 = __builtin_elementwise_fma(v2, m, c); v3 = __builtin_elementwise_fma(v3, m, c);
+            v4 = __builtin_elementwise_fma(v4, m, c); v5 = __builtin_elementwise_fma(v5, m, c);
+            v6 = __builtin_elementwise_fma(v6, m, c); v7 = __builtin_elementwise_fma(v7, m, c);
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = v0.x + v1.x + v2.y + v3.x + v4.x + v5.y + v6.x + v7.x;
+}
+
+int main() {
+    float *dA, *dB, *dC, *out;
+    const int SMAX = 256;
+    (void)hipMalloc(&dA, 32 * 16 * SMAX * 4); (void)hipMalloc(&dB, 32 * 16 * SMAX * 4); (void)hipMalloc(&dC, 1024 * 4);
+    (void)hipMalloc(&out, 2048 * 256 * 4);
+    srand(7);
+    for (int S : {4, 32, 256}) {
+        std::vector<float> A(32 * 16 * S), B(16 * S * 32), C(1024);
+        for (auto &v : A) { v = (float)rand() / RAND_MAX; if (rand() % 4 == 0) v *= 1e-4f; }    // D_hat-like: [0, 1], some tiny
+        for (auto &v : B) v = 0.01f + 3.f * (float)rand() / RAND_MAX;
+        (void)hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, 0, dC, dA, dB, S);
+        (void)hipMemcpy(C.data(), dC, 1024 * 4, hipMemcpyDeviceToHost);
+        double bias = 0, rms = 0, mx = 0, rms32 = 0;
+        for (int m = 0; m < 32; ++m)
+            for (int n = 0; n < 32; ++n) {
+                double ex = 0; float chain = 0.f;
+                for (int k = 0; k < 16 * S; ++k) { ex += (double)A[m * 16 * S + k] * (double)B[k * 32 + n]; chain = fmaf(A[m * 16 * S + k], B[k * 32 + n], chain); }
+                const double rel = (C[m * 32 + n] - ex) / ex, rel32 = (chain - ex) / ex;
+                bias += rel; rms += rel * rel; mx = fmax(mx, fabs(rel)); rms32 += rel32 * rel32;
+            }
+        printf("%5d terms: bf16x3 (6 products): mean signed rel err %+.3e  rms %.3e  max %.3e   | float32 fma chain rms %.3e\n",
+               16 * S, bias / 1024, sqrt(rms / 1024), mx, sqrt(rms32 / 1024));
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto timeit = [&](auto launch) { float ms = 0; for (int rep = 0; rep < 3; ++rep) { (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); } return ms; };
+    const int iters = 4000;
+    float t;
+    t = timeit([&] { hipLaunchKernelGGL(k_rate<0>, dim3(2048), dim3(256), 0, 0, out, iters); });
+    printf("v_mfma_f32_32x32x16_bf16, 2048 groups: %.2f ms, %.0f TFLOP/s\n", t, 2048.0 * 4 * iters * 8 * 32768.0 / t * 1e-9);
+    t = timeit([&] { hipLaunchKernelGGL(k_rate<0>, dim3(256), dim3(256), 0, 0, out, iters); });
+    printf("one wave per SIMD: matrix only %.3f ms", t);
+    t = timeit([&] { hipLaunchKernelGGL(k_valu, dim3(256), dim3(256), 0, 0, out, iters); });
+    printf(", 8 v_pk_fma_f32 per matrix instruction only %.3f ms", t);
+    t = timeit([&] { hipLaunchKernelGGL(k_rate<8>, dim3(256), dim3(256), 0, 0, out, iters); });
+    printf(", interleaved %.3f ms", t);
+    t = timeit([&] { hipLaunchKernelGGL(k_rate<16>, dim3(256), dim3(256), 0, 0, out, iters); });
+    printf(", interleaved with 16: %.3f ms\n", t);
+    float t0 = timeit([&] { hipLaunchKernelGGL((k_mix<0, 0>), dim3(256), dim3(256), 0, 0, out, iters); });
+    float t1 = timeit([&] { hipLaunchKernelGGL((k_mix<0, 1>), dim3(256), dim3(256), 0, 0, out, iters); });
+    printf("8 v_fma_f32 per matrix instruction: alone %.3f ms, interleaved %.3f ms\n", t0, t1);
+    t0 = timeit([&] { hipLaunchKernelGGL((k_mix<1, 0>), dim3(256), dim3(256), 0, 0, out, iters); });
+    t1 = timeit([&] { hipLaunchKernelGGL((k_mix<1, 1>), dim3(256), dim3(256), 0, 0, out, iters); });
+    printf("8 x (and, sub, xor, perm, add) per matrix instruction: alone %.3f ms, interleaved %.3f ms\n", t0, t1);
+    for (int threads = 256; threads <= 512; threads += 256) {
+        const float m0 = timeit([&] { hipLaunchKernelGGL((k_mix<0, 0>), dim3(256), dim3(threads), 0, 0, out, iters); });
+        const float m1 = timeit([&] { hipLaunchKernelGGL((k_mix<0, 1>), dim3(256), dim3(threads), 0, 0, out, iters); });
+        const float m2 = timeit([&] { hipLaunchKernelGGL((k_mix<1, 0>), dim3(256), dim3(threads), 0, 0, out, iters); });
+        const float m3 = timeit([&] { hipLaunchKernelGGL((k_mix<1, 1>), dim3(256), dim3(threads), 0, 0, out, iters); });
+        printf("%d wave(s) per SIMD, each: 8 v_fma_f32 alone %.3f / with matrix instr %.3f ms;  integer mix alone %.3f / with matrix instr %.3f ms\n",
+               threads / 256, m0, m1, m2, m3);
+    }
+    return 0;
+}

@@ -53,6 +53,22 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// one / two dependent chains per wave (1 or 2 waves per SIMD): does a chain on ONE accumulator keep the matrix pipe full?
+template <int CHAINS>
+__global__ __launch_bounds__(256) void k_chain_rate(float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16v a0 = {0}, a1 = a0;
+    const float x = 1.0f + lane * 1e-3f, y = 1.0f - lane * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+            if (CHAINS == 2) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[1];
+}
+
 int main() {
     float *dA, *dB, *dC, *out;
     const int SMAX = 4096;
@@ -103,5 +119,20 @@ int main() {
         const double flops = (double)blocks * 4 * iters * 16 * (f64 ? 2.0 * 16 * 16 * 4 : 2.0 * 32 * 32 * 2);
         printf("%s: %.2f ms, %.1f TFLOP/s\n", f64 ? "v_mfma_f64_16x16x4_f64 " : "v_mfma_f32_32x32x2_f32", ms, flops / ms * 1e-9);
     }
+    for (int chains = 1; chains <= 2; ++chains)
+        for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu) {
+            float ms = 0;
+            const int iters = 20000, blocks = 256 * wg_per_cu;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0);
+                if (chains == 1) hipLaunchKernelGGL(k_chain_rate<1>, dim3(blocks), dim3(256), 0, 0, out, iters);
+                else hipLaunchKernelGGL(k_chain_rate<2>, dim3(blocks), dim3(256), 0, 0, out, iters);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms, e0, e1);
+            }
+            const double n_mfma = (double)iters * 8 * chains;
+            printf("%d dependent chain(s), %d wave(s) per SIMD: %.1f ns per matrix instruction and wave, %.1f TFLOP/s\n", chains,
+                   wg_per_cu, ms * 1e6 / n_mfma, (double)blocks * 4 * n_mfma * 4096.0 / ms * 1e-9);
+        }
     return 0;
 }

@@ -315,10 +315,19 @@ int oriana_dense_times_factor(double *out, const float *D, const double *W, int6
  * given or both NULL -- DV_next[n, K] += D_hat V_next[m, K] from the tile of D_hat still in registers: with V_next the
  * factor the NEXT sweep's cell update multiplies (zigap.py:116: the V_hat just updated; sparse_zigap.py:138:
  * S_hat * Vprime_hat) that sweep has no pass over D_hat left on the cell side.  DV_next must be zeroed first.
- * scratch_m: m floats of device scratch (logit(pi_d) in float32). */
+ * scratch: oriana_dropout_sweep_scratch_floats(m, K) floats of device scratch (logit(pi_d), float32 copies of V and
+ * V_next).  arithmetic: how the float32 products are evaluated --
+ *   ORIANA_MATRIX_F32     v_mfma_f32_32x32x2_f32 (a chain of single-rounding float32 FMAs);
+ *   ORIANA_MATRIX_BF16X3  each float32 operand split into three bf16, six cross products on the bf16 matrix cores,
+ *                         float32 accumulation (K <= 64; larger K silently take the float32 instruction): the same
+ *                         error as the float32 chain on sums of <= 512 terms (which is all the kernel forms before it
+ *                         leaves the matrix core), 2.7 x its rate. */
+#define ORIANA_MATRIX_F32     0
+#define ORIANA_MATRIX_BF16X3  1
 int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d,
                                const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
-                               float *scratch_m, int64_t n, int64_t m, int64_t K, void *stream);
+                               float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K, void *stream);
+int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K);
 /* out[m, K] += D_hat^T W[n, K] (zigap.py:124), D_hat streamed once; `out` must be initialised. */
 int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
                                     void *stream);

@@ -487,6 +487,331 @@ __global__ __launch_bounds__(256, (NT < 4) ? 2 : 1) void k_dt_times_factor_f32(d
             }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same sweep kernel with every float32 product evaluated on the bf16 matrix cores: x = hi + mid + lo (three bf16,
+// 24 bits, split by truncation so that the remainders are exact) and six of the nine cross products
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the three dropped ones are below 2^-24 of the product), accumulated in
+// float32 by v_mfma_f32_32x32x16_bf16.  tools/ubench/mfma_bf16x3.hip: the error of a sum of <= 512 positive terms is
+// that of the float32 FMA chain (2.9e-7 rms at 512), at 2.7 x the rate of v_mfma_f32_32x32x2_f32 after the six-fold
+// overhead.  K <= 64.  Fragment map of v_mfma_f32_32x32x16_bf16: A[m = lane & 31][k = 8 (lane >> 5) + e],
+// B[k = 8 (lane >> 5) + e][n = lane & 31], e = 0..7 the eight bf16 (four dwords) of the lane; D as for the float32
+// 32 x 32 instructions.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f16v mfma_b16(u4v a, u4v b, f16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+// two floats -> their (hi, mid, lo) bf16 parts, each pair packed in one dword (x0 in the low half)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);
+    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(c1 & 0xFFFF0000u);
+    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// eight floats -> three operand registers (hi, mid, lo)
+__device__ __forceinline__ void split8(const float (&x)[8], u4v (&o)[3]) {
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+        uint32_t a, b, c2;
+        split2(x[2 * w2], x[2 * w2 + 1], a, b, c2);
+        o[0][w2] = a; o[1][w2] = b; o[2][w2] = c2;
+    }
+}
+
+// the six cross products, small terms first
+#define ORIANA_MF6(ACC, A, B)                                                                          \
+    do {                                                                                               \
+        ACC = mfma_b16(A[2], B[0], ACC); ACC = mfma_b16(A[0], B[2], ACC); ACC = mfma_b16(A[1], B[1], ACC); \
+        ACC = mfma_b16(A[1], B[0], ACC); ACC = mfma_b16(A[0], B[1], ACC); ACC = mfma_b16(A[0], B[0], ACC); \
+    } while (0)
+
+// LDS carve-up of k_dropout_sweep_b16 (bytes): operand images are [..][split][lane] x 16 bytes
+struct B16Lds {
+    int vt, v2, mt, tb, cs, total;
+    __host__ __device__ B16Lds(int KC, int NT) {
+        int o = 0;
+        vt = o; o += 2 * KC * 3 * 64 * 16;           // [buf][k chunk][split][lane]: A operand of Lambda^T = V U^T
+        v2 = o; o += 2 * NT * 2 * 3 * 64 * 16;       // [buf][n tile][instruction][split][lane]: B operand of D V_next
+        mt = o; o += 2 * 4 * 32 * 2 * 4;             // [buf][wave][32 genes] {logit(pi_d), mask word}
+        tb = o; o += 4 * 32 * TS * 4;                // [wave][32 cells][32 genes] transpose buffer
+        cs = o; o += 2 * 4 * 32 * 4;                 // [parity][wave][32 genes] column partial sums
+        total = o;
+    }
+};
+
+// The operand images of a gene tile are the same for every row block: they are built ONCE per sweep, in the layout
+// the kernel copies into LDS, by this pre-kernel (one work-group per tile of 32 genes):
+//   first image  [k chunk][split][lane = 32 (G & 1) + g]: V[g][8 G .. 8 G + 7], thread (g = tid & 31, G = tid >> 5);
+//   second image [n tile][instruction q][split][lane = 32 hh + cc]: V_next[gene(q, hh, e)][32 nt + cc], e = 0..7, the
+//                genes in the order the accumulator registers of the first product hold them (acc_row).
+template <int NT, int KC>
+__global__ __launch_bounds__(256) void k_split_images(u4v *__restrict__ img1, u4v *__restrict__ img2,
+                                                      const double *__restrict__ V, const double *__restrict__ Vn,
+                                                      int64_t m, int K) {
+    const int tid = threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.x * 32;
+    {
+        const int g = tid & 31, G = tid >> 5;
+        if (G < 2 * KC) {
+            const int64_t j = j0 + g;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 8 * G + e;
+                x[e] = (j < m && kk < K) ? (float)V[j * K + kk] : 0.f;
+            }
+            u4v o[3];
+            split8(x, o);
+            u4v *dst = img1 + (int64_t)blockIdx.x * (KC * 3 * 64) + ((G >> 1) * 3) * 64 + (G & 1) * 32 + g;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) dst[sp * 64] = o[sp];
+        }
+    }
+    if (Vn) {
+        const int nt = tid >> 7, q = (tid >> 6) & 1, hh = (tid >> 5) & 1, cc = tid & 31;
+        if (nt < NT) {
+            const int kk = nt * 32 + cc;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t j = j0 + acc_row(8 * q + e, hh);
+                x[e] = (j < m && kk < K) ? (float)Vn[j * K + kk] : 0.f;
+            }
+            u4v o[3];
+            split8(x, o);
+            u4v *dst = img2 + (int64_t)blockIdx.x * (NT * 2 * 3 * 64) + ((nt * 2 + q) * 3) * 64 + hh * 32 + cc;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) dst[sp * 64] = o[sp];
+        }
+    }
+}
+
+template <int NT, int KC>
+__global__ __launch_bounds__(256, 2) void k_dropout_sweep_b16(float *__restrict__ D_hat, const double *__restrict__ U,
+                                                              const u4v *__restrict__ img1, const float *__restrict__ lgit,
+                                                              const uint32_t *__restrict__ nzmask,
+                                                              double *__restrict__ colsum, const u4v *__restrict__ img2,
+                                                              double *__restrict__ DV, int64_t n, int64_t m, int K,
+                                                              int64_t j_per_split) {
+    extern __shared__ float lds[];
+    char *ldsb = reinterpret_cast<char *>(lds);
+    const B16Lds L(KC, NT);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int64_t i0w = (int64_t)blockIdx.x * 128 + w * 32;
+    const int64_t jb = (int64_t)blockIdx.y * j_per_split;
+    const int64_t je = (jb + j_per_split < m) ? jb + j_per_split : m;
+    float *T = reinterpret_cast<float *>(ldsb + L.tb) + w * 32 * TS;
+    u4v *vt_img = reinterpret_cast<u4v *>(ldsb + L.vt);
+    u4v *v2_img = reinterpret_cast<u4v *>(ldsb + L.v2);
+
+    // the wave's strip of U_hat as the B operand of the first product: per k chunk, factors 16 kc + 8 h + e of cell c
+    u4v ub[KC][3];
+    {
+        const int64_t i = i0w + c;
+        const double *urow = U + (i < n ? i : n - 1) * K;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * kc + 8 * h + e;
+                x[e] = (i < n && kk < K) ? (float)urow[kk < K ? kk : K - 1] : 0.f;
+            }
+            split8(x, ub[kc]);
+        }
+    }
+
+    // Staging of one gene tile: straight 16-byte copies of the two operand images k_split_images has built (loads at
+    // the top of the previous tile, consumed right before that tile's stores: see k_dropout_sweep).
+    constexpr int N1 = KC * 3 * 64, N2 = NT * 2 * 3 * 64;        // 16-byte pieces per image
+    constexpr int R1 = (N1 + 255) / 256, R2 = (N2 + 255) / 256;
+    const bool has_next = img2 != nullptr;
+    u4v sreg[R1], nreg[R2];
+    uint32_t mkreg = 0;
+    auto stage_load = [&](int64_t j0) {
+        const int64_t tile = j0 >> 5;
+        const u4v *s1 = img1 + tile * N1;
+#pragma unroll
+        for (int r = 0; r < R1; ++r) { const int idx = tid + 256 * r; sreg[r] = s1[idx < N1 ? idx : N1 - 1]; }
+        if (has_next) {
+            const u4v *s2 = img2 + tile * N2;
+#pragma unroll
+            for (int r = 0; r < R2; ++r) { const int idx = tid + 256 * r; nreg[r] = s2[idx < N2 ? idx : N2 - 1]; }
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < R1; ++r) { const int idx = tid + 256 * r; if (N1 % 256 == 0 || idx < N1) vt_img[buf * N1 + idx] = sreg[r]; }
+        if (has_next) {
+#pragma unroll
+            for (int r = 0; r < R2; ++r) { const int idx = tid + 256 * r; if (N2 % 256 == 0 || idx < N2) v2_img[buf * N2 + idx] = nreg[r]; }
+        }
+    };
+    const int mw = (tid >> 5) & 3;
+    const int64_t mrow = ((int64_t)blockIdx.x * 128 + mw * 32) >> 5;
+    const bool mrow_ok = nzmask && (int64_t)blockIdx.x * 128 + mw * 32 < n;
+    float lgreg = 0.f;
+    auto meta_load = [&](int64_t j0) {
+        if (tid < 128) {
+            const int64_t jj = j0 + (tid & 31);
+            const int64_t jc = jj < je ? jj : je - 1;
+            lgreg = lgit[jc];
+            mkreg = mrow_ok ? nzmask[mrow * m + jc] : 0u;
+        }
+    };
+    auto meta_store = [&](int buf) {
+        if (tid < 128) {
+            float2 pr;
+            pr.x = lgreg;
+            pr.y = __uint_as_float(mkreg);
+            *reinterpret_cast<float2 *>(ldsb + L.mt + (((buf * 4 + mw) * 32 + (tid & 31)) * 2) * 4) = pr;
+        }
+    };
+
+    f16v dv[NT], dvs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { dv[nt][v] = 0.f; dvs[nt][v] = 0.f; }
+    }
+    const bool rowok = i0w + c < n;
+    const bool vec_ok = (m & 3) == 0;
+    float *csb = reinterpret_cast<float *>(ldsb + L.cs);
+
+    if (jb < je) {
+        stage_load(jb);
+        meta_load(jb);
+        stage_store(0);
+        meta_store(0);
+    }
+    __syncthreads();
+    int buf = 0, par = 0, since_flush = 0;
+    auto colsum_flush = [&](int64_t jt, int parity) {
+        if (colsum && w == 0 && lane < 32 && jt + lane < je) {
+            const float *cs = csb + parity * 4 * 32 + lane;
+            atomicAdd(&colsum[jt + lane], (double)cs[0] + (double)cs[32] + (double)cs[64] + (double)cs[96]);
+        }
+    };
+    for (int64_t j0 = jb; j0 < je; j0 += 32) {
+        const bool more = j0 + 32 < je;
+        { const int64_t jn = more ? j0 + 32 : j0; stage_load(jn); meta_load(jn); }   // (the last tile again: unused)
+        if (j0 > jb) colsum_flush(j0 - 32, par ^ 1);
+        ORIANA_VMEM_FENCE();
+        // ---- Lambda^T = V U^T
+        f16v l0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) l0[v] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u4v *src = vt_img + buf * N1 + (kc * 3) * 64 + lane;
+            u4v a[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) a[sp] = src[sp * 64];
+            ORIANA_MF6(l0, a, ub[kc]);
+        }
+        // ---- sigmoid, overrides
+        const int jrem = (je - j0 < 32) ? (int)(je - j0) : 32;
+        const float2 *mts = reinterpret_cast<const float2 *>(ldsb + L.mt) + (buf * 4 + w) * 32;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float2 mt = mts[acc_row(v, h)];
+            if ((v & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const float x = mt.x - l0[v];
+            float p = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+            if (mt.x == -INFINITY) p = 1e-10f;                   // pi_d <= 0                         zigap.py:133
+            if ((__float_as_uint(mt.y) >> c) & 1u) p = 1.0f;     // X != 0: f32(1 - 1e-10) == 1       zigap.py:135
+            l0[v] = p;
+        }
+        if (!(jrem == 32 && i0w + 32 <= n)) {                    // (uniform) padding never reaches a sum
+#pragma unroll
+            for (int v = 0; v < 16; ++v) if (!rowok || acc_row(v, h) >= jrem) l0[v] = 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) T[c * TS + acc_row(v, h)] = l0[v];
+        __builtin_amdgcn_wave_barrier();
+        stage_store(buf ^ 1);
+        meta_store(buf ^ 1);
+        ORIANA_VMEM_FENCE();
+        // ---- D_hat rows out, column sums of the tile
+        {
+            const int gq = (lane & 7) * 4;
+            const bool full = vec_ok && jrem == 32;
+            f4v csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = (lane >> 3) + 8 * q;
+                const f4v t = *reinterpret_cast<const f4v *>(T + r * TS + gq);
+                csum += t;
+                const int64_t i = i0w + r;
+                if (D_hat && i < n) {
+                    float *dst = D_hat + i * m + j0 + gq;
+                    if (full) *reinterpret_cast<f4v *>(dst) = t;
+                    else {
+                        if (gq + 0 < jrem) dst[0] = t.x;
+                        if (gq + 1 < jrem) dst[1] = t.y;
+                        if (gq + 2 < jrem) dst[2] = t.z;
+                        if (gq + 3 < jrem) dst[3] = t.w;
+                    }
+                }
+            }
+            if (colsum) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                    csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+                }
+                if (lane < 8) *reinterpret_cast<f4v *>(csb + (par * 4 + w) * 32 + gq) = csum;
+            }
+        }
+        // ---- DV += D V_next: the accumulator registers 8 q .. 8 q + 7 are the eight k slots of instruction q
+        if (has_next) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = l0[8 * q + e];
+                u4v a[3];
+                split8(x, a);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u4v *src = v2_img + buf * N2 + ((nt * 2 + q) * 3) * 64 + lane;
+                    u4v b[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) b[sp] = src[sp * 64];
+                    ORIANA_MF6(dv[nt], a, b);
+                }
+            }
+            if (++since_flush == 8) {                            // 256 genes: leave the matrix core
+                since_flush = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { dvs[nt][v] += dv[nt][v]; dv[nt][v] = 0.f; }
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+        par ^= 1;
+    }
+    if (jb < je) colsum_flush(jb + ((je - jb - 1) / 32) * 32, par ^ 1);
+    if (has_next && DV) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int64_t i = i0w + acc_row(v, h);
+                const int k = nt * 32 + c;
+                if (i < n && k < K) atomicAdd(&DV[i * K + k], (double)dvs[nt][v] + (double)dv[nt][v]);
+            }
+    }
+}
+
 // Number of ranges to cut the reduction (or gene) axis into, given `blocks` work-groups along the other axis: the
 // grid runs in rounds of 512 resident work-groups (2 per CU), and a last round that is nearly empty costs as much as a
 // full one -- 1580 groups take 4 rounds at 77 %.  Among 4 to 12 rounds' worth, the count that leaves the last round
@@ -537,6 +862,33 @@ static int launch_sweep(float *D_hat, const double *U, const double *V, const fl
     return 0;
 }
 
+// scratch of oriana_dropout_sweep_fused (floats): logit(pi_d) [m rounded up to 64] | first images | second images
+static inline int64_t b16_img_floats(int64_t m, int pieces) { return ((m + 31) / 32) * (int64_t)pieces * 4; }
+
+template <int NT, int KC>
+static int launch_sweep_b16(float *D_hat, const double *U, const double *V, const float *lg, const uint32_t *nzmask,
+                            double *colsum, const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m,
+                            int K, hipStream_t st) {
+    const B16Lds L(KC, NT);
+    const size_t lds = (size_t)L.total;
+    u4v *img1 = reinterpret_cast<u4v *>(img_scratch);
+    u4v *img2 = Vn ? reinterpret_cast<u4v *>(img_scratch + b16_img_floats(m, KC * 3 * 64)) : nullptr;
+    hipLaunchKernelGGL((k_split_images<NT, KC>), dim3((unsigned)((m + 31) / 32)), dim3(256), 0, st, img1, img2, V, Vn, m, K);
+    const int64_t rb = (n + 127) / 128;
+    const int64_t splits0 = pick_splits(rb, (m + 255) / 256);
+    int64_t jps = (m + splits0 - 1) / splits0;
+    jps = (jps + 31) / 32 * 32;
+    const int64_t splits = (m + jps - 1) / jps;
+    if (splits > 65535 || rb > 0x7fffffffLL) return ORIANA_EINVAL;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_dropout_sweep_b16<NT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -1000 - (int)e;
+    }
+    hipLaunchKernelGGL((k_dropout_sweep_b16<NT, KC>), dim3((unsigned)rb, (unsigned)splits), dim3(256), lds, st, D_hat, U,
+                       (const u4v *)img1, lg, nzmask, colsum, (const u4v *)img2, DV, n, m, K, jps);
+    return 0;
+}
+
 template <int NT, int GQ>
 static int launch_dt(double *out, const float *D, const double *W, int64_t n, int64_t m, int K, hipStream_t st) {
     const int64_t jb = (m + 128 * GQ - 1) / (128 * GQ);
@@ -554,22 +906,40 @@ static int launch_dt(double *out, const float *D, const double *W, int64_t n, in
 
 using namespace oriana;
 
+extern "C" int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K) {
+    if (m < 0 || K < 0) return 0;
+    // logit(pi_d) + the two operand images of the bf16 path at their largest (K <= 64: 4 k chunks, 2 n tiles)
+    return (m + 63) / 64 * 64 + b16_img_floats(m, 4 * 3 * 64) + b16_img_floats(m, 2 * 2 * 3 * 64);
+}
+
 extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d64,
                                           const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
-                                          float *scratch_m, int64_t n, int64_t m, int64_t K, void *stream) {
+                                          float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K, void *stream) {
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (K > 128) return ORIANA_EKRANGE;
     if (n == 0 || m == 0) return 0;
-    if (!D_hat || !U || !V || !pi_d64 || !scratch_m || ((V_next == nullptr) != (DV_next == nullptr))) return ORIANA_EINVAL;
+    if (!D_hat || !U || !V || !pi_d64 || !scratch || ((V_next == nullptr) != (DV_next == nullptr))) return ORIANA_EINVAL;
+    if (((uintptr_t)scratch & 15) != 0) return ORIANA_EINVAL;
+    if (arithmetic != ORIANA_MATRIX_F32 && arithmetic != ORIANA_MATRIX_BF16X3) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch_m, pi_d64, m);
-    const float *pi_d = scratch_m;
+    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, pi_d64, m);
+    const float *pi_d = scratch;
     int rc;
-    switch ((int)((K + 31) / 32)) {
-        case 1: rc = launch_sweep<1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
-        case 2: rc = launch_sweep<2>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
-        case 3: rc = launch_sweep<3>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
-        default: rc = launch_sweep<4>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
+        float *img = scratch + (m + 63) / 64 * 64;
+        switch ((int)((K + 15) / 16)) {
+            case 1: rc = launch_sweep_b16<1, 1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
+            case 2: rc = launch_sweep_b16<1, 2>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
+            case 3: rc = launch_sweep_b16<2, 3>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
+            default: rc = launch_sweep_b16<2, 4>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
+        }
+    } else {
+        switch ((int)((K + 31) / 32)) {
+            case 1: rc = launch_sweep<1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
+            case 2: rc = launch_sweep<2>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
+            case 3: rc = launch_sweep<3>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
+            default: rc = launch_sweep<4>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
+        }
     }
     if (rc) return rc;
     ORIANA_LAUNCH_CHECK();

@@ -49,7 +49,11 @@ class _ZIMixin:
         self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
         self._DV_next = None
         self.n_kept_products = 0          # sweeps whose D_hat V came from the previous sweep's D update
-        self._lg_scratch = torch.zeros(max(m, 1), dtype=torch.float32, device=dev)
+        from .. import _lib
+        self._lg_scratch = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, self.k)), dtype=torch.float32, device=dev)
+        # how the float32 products are evaluated (include/oriana_hip.h): 1 = three-way bf16 splits on the bf16 matrix
+        # cores (K <= 64), 0 = the float32 matrix instruction
+        self._matrix_arith = {'f32': 0, 'bf16x3': 1}[os.environ.get('ORIANA_ZI_MATRIX', 'bf16x3')]
 
     @property
     def D_hat(self):
@@ -125,8 +129,8 @@ class _ZIMixin:
                     DV = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
                     V_next = V_next.contiguous()
                 call('oriana_dropout_sweep_fused', ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
-                     ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self.n, self.m,
-                     self.k, stream_ptr())
+                     ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self._matrix_arith,
+                     self.n, self.m, self.k, stream_ptr())
             else:
                 DV = None
                 call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),

@@ -524,9 +524,12 @@ def test_dense_t_times_factor_f32(n, m, K):
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,m,K', F32_SHAPES)
 @pytest.mark.parametrize('with_next', [True, False])
-def test_dropout_sweep_fused_matches_float64(n, m, K, with_next):
-    """oriana_dropout_sweep_fused against the float64 kernels: D_hat, the column sums of p_d, and D_hat V_next."""
+@pytest.mark.parametrize('arithmetic', [0, 1], ids=['f32', 'bf16x3'])
+def test_dropout_sweep_fused_matches_float64(n, m, K, with_next, arithmetic):
+    """oriana_dropout_sweep_fused against the float64 kernels: D_hat, the column sums of p_d, and D_hat V_next, with
+    the float32 matrix instruction and with three-way bf16 splits on the bf16 matrix cores (K <= 64)."""
     import torch
+    from oriana_amd import _lib
     from oriana_amd._lib import call, ptr, stream_ptr
     g = torch.Generator(device='cpu').manual_seed(n + 3 * m + 11 * K)
     U = (torch.rand(n, K, generator=g, dtype=torch.float64) * 2.0).cuda()
@@ -543,9 +546,9 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next):
     D1 = torch.full((n, m), -7.0, dtype=torch.float32, device='cuda')
     cs1 = torch.zeros(m, dtype=torch.float64, device='cuda')
     DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
-    lgs = torch.zeros(m, dtype=torch.float32, device='cuda')
+    lgs = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
     call('oriana_dropout_sweep_fused', ptr(D1), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs1),
-         ptr(Vn) if with_next else None, ptr(DV) if with_next else None, ptr(lgs), n, m, K, stream_ptr())
+         ptr(Vn) if with_next else None, ptr(DV) if with_next else None, ptr(lgs), arithmetic, n, m, K, stream_ptr())
     D2 = torch.empty_like(D1)
     cs2 = torch.zeros_like(cs1)
     call('oriana_dropout_update_fused', None, ptr(D2), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs2), n, m, K, stream_ptr())
@@ -553,7 +556,8 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next):
     d1, d2 = D1.cpu().numpy(), D2.cpu().numpy()
     # Lambda carries K float32 roundings (<= 1e-7 K^0.5 |Lambda| absolute in the exponent), the sigmoid two more ulp
     lam_max = float((U @ V.t()).max())
-    assert np.max(np.abs(d1 - d2) / np.maximum(d2, 1e-30) * (d2 > 1e-30)) < 4e-7 * max(1.0, lam_max)
+    # (the six-product bf16 form of a float32 product drops terms below 2^-24 of it: a slightly wider bound there)
+    assert np.max(np.abs(d1 - d2) / np.maximum(d2, 1e-30) * (d2 > 1e-30)) < (6e-7 if arithmetic else 4e-7) * max(1.0, lam_max)
     np.testing.assert_allclose(d1, d2, rtol=0, atol=3e-7)
     Xh = X.cpu().numpy()
     assert np.all(d1[Xh != 0] == 1.0)                                     # the overrides are exact
@@ -578,7 +582,8 @@ def test_f32_dense_entries_reject_large_K():
     f = torch.zeros(4, device='cuda', dtype=torch.float32)
     L = _lib.load()
     assert L.oriana_dense_t_times_factor_f32(ptr(t), ptr(f), ptr(t), 1, 1, 129, None) == -2
-    assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, ptr(f), 1, 1, 129, None) == -2
+    assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, ptr(f), 0, 1, 1, 129, None) == -2
+    assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, ptr(f), 7, 1, 1, 1, None) == -1
 
 
 @pytest.mark.parametrize('K,m', [(100, 700), (96, 300), (20, 530), (64, 513), (200, 300)])

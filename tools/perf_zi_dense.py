@@ -21,7 +21,8 @@ call('oriana_nzmask_f32', ptr(mask), ptr((D < 0.1).float()), n, m, stream_ptr())
 cs = torch.zeros(m, dtype=torch.float64, device=dev)
 o1 = torch.zeros(n, K, dtype=torch.float64, device=dev)
 o2 = torch.zeros(m, K, dtype=torch.float64, device=dev)
-lgs = torch.zeros(m, dtype=torch.float32, device=dev)
+from oriana_amd import _lib   # noqa: E402
+lgs = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device=dev)
 
 
 def timeit(f, reps=5):
@@ -36,10 +37,13 @@ def timeit(f, reps=5):
 
 st = stream_ptr()
 rows = []
-t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), n, m, K, st))
+if K <= 64:
+    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), 1, n, m, K, st))
+    rows.append(('bf16x3  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K + 31) // 32)) / t / 1e9, 4.0 * n * m / t / 1e9))
+t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), 0, n, m, K, st))
 rows.append(('f32  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K + 31) // 32)) / t / 1e9, 4.0 * n * m / t / 1e9))
 if '--shipped-only' not in sys.argv:       # (counter runs: only the two kernels a sweep launches)
-    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), None, None, ptr(lgs), n, m, K, st))
+    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), None, None, ptr(lgs), 0, n, m, K, st))
     rows.append(('f32  D update alone', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
 t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), n, m, K, st))
 rows.append(('f32  D^T U', t, 2.0 * n * m * 32 * ((K + 31) // 32) / t / 1e9, 4.0 * n * m / t / 1e9))

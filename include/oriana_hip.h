@@ -328,9 +328,12 @@ int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, c
                                const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
                                float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K, void *stream);
 int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K);
-/* out[m, K] += D_hat^T W[n, K] (zigap.py:124), D_hat streamed once; `out` must be initialised. */
-int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, int64_t n, int64_t m, int64_t K,
-                                    void *stream);
+/* out[m, K] += D_hat^T W[n, K] (zigap.py:124), D_hat streamed once; `out` must be initialised.  arithmetic as above;
+ * scratch: oriana_dense_t_scratch_floats(n, K) floats (16-byte aligned; the bf16 operand images of W), may be NULL
+ * with ORIANA_MATRIX_F32. */
+int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, float *scratch, int arithmetic,
+                                    int64_t n, int64_t m, int64_t K, void *stream);
+int64_t oriana_dense_t_scratch_floats(int64_t n, int64_t K);
 /* either output may be NULL */
 int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
 int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);

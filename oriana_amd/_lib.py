@@ -56,7 +56,8 @@ _SIGS = {
     'oriana_dense_times_factor': (c_int, [_P, _P, _P, _I, _I, _I, c_int, _P]),
     'oriana_dropout_sweep_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _I, _I, _I, _P]),
     'oriana_dropout_sweep_scratch_floats': (_I, [_I, _I]),
-    'oriana_dense_t_times_factor_f32': (c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    'oriana_dense_t_times_factor_f32': (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _P]),
+    'oriana_dense_t_scratch_floats': (_I, [_I, _I]),
     'oriana_factor_cast_f32': (c_int, [_P, _P, _P, _P, _I, _I, _P]),
     'oriana_metric_nnz': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _P]),
     'oriana_count_stats': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P]),

@@ -862,6 +862,154 @@ static int launch_sweep(float *D_hat, const double *U, const double *V, const fl
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// out[j, k] += sum_i D[i, j] W[i, k] with the products on the bf16 matrix cores (three-way splits, six cross products).
+// W is split ONCE per call into per-chunk operand images (k_split_rows: 16 rows per chunk, [n tile][split][lane =
+// 32 hh + cc]: W[16 chunk + 8 hh + e][32 nt + cc], e = 0..7); D is split on the fly -- it is read exactly once.
+// A wave owns 32 genes x NT * 32 factors: A[m = gene c][k = cell 8 h + e] comes from eight 4-byte loads per lane and
+// chunk (128-byte row pieces per half-wave), four chunks ahead in a register ring; B from the staged images.
+template <int NT>
+__global__ __launch_bounds__(256) void k_split_rows(u4v *__restrict__ img, const double *__restrict__ W, int64_t n, int K) {
+    const int tid = threadIdx.x;
+    const int nt = tid >> 6, hh = (tid >> 5) & 1, cc = tid & 31;
+    if (nt >= NT) return;
+    const int64_t i0 = (int64_t)blockIdx.x * 16 + 8 * hh;
+    const int kk = nt * 32 + cc;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (i0 + e < n && kk < K) ? (float)W[(i0 + e) * K + kk] : 0.f;
+    u4v o[3];
+    split8(x, o);
+    u4v *dst = img + (int64_t)blockIdx.x * (NT * 3 * 64) + (nt * 3) * 64 + hh * 32 + cc;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) dst[sp * 64] = o[sp];
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restrict__ out, const float *__restrict__ D,
+                                                                const u4v *__restrict__ img, int64_t n, int64_t m, int K,
+                                                                int64_t i_per_split) {
+    constexpr int CH = 2;                                        // chunks (of 16 rows) per staged group and in the ring
+                                                                 // (4: > 256 registers, the slow path's index arithmetic)
+    constexpr int NP = NT * 3 * 64;                              // 16-byte pieces per chunk image
+    constexpr int RS = (CH * NP + 255) / 256;                    // staged pieces per thread and group
+    __shared__ u4v Ws[2][CH * NP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 31, h = lane >> 5;
+    const int64_t jw = ((int64_t)blockIdx.x * 4 + w) * 32;
+    const int64_t ib = (int64_t)blockIdx.y * i_per_split;       // multiple of 64 (whole groups)
+    const int64_t ie = (ib + i_per_split < n) ? ib + i_per_split : n;
+    const int64_t j = jw + c;
+
+    f16v acc[NT], accs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc[nt][v] = 0.f; accs[nt][v] = 0.f; }
+
+    u4v wreg[RS];
+    auto stage_load = [&](int64_t i0) {                         // (i0 a multiple of 64; images exist for every chunk of n)
+        const u4v *src = img + (i0 >> 4) * NP;
+        const int64_t avail = (((n + 15) >> 4) - (i0 >> 4)) * NP;           // pieces left in the image array
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int idx = tid + 256 * r;
+            wreg[r] = src[(idx < CH * NP && idx < avail) ? idx : 0];
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) { const int idx = tid + 256 * r; if ((CH * NP) % 256 == 0 || idx < CH * NP) Ws[buf][idx] = wreg[r]; }
+    };
+    float ring[CH][8];
+    auto load_checked = [&](float (&x)[8], int64_t i0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t i = i0 + 8 * h + e;
+            x[e] = (i < ie && j < m) ? D[i * m + j] : 0.f;
+        }
+    };
+    const bool wave_fast = jw + 32 <= m;
+    if (ib < ie) {
+        stage_load(ib);
+        stage_store(0);
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) load_checked(ring[ch], ib + 16 * ch);
+    }
+    __syncthreads();
+    int buf = 0, groups = 0;
+    // one staged group = CH chunks; FAST: every row the ring will ask for exists and the wave's genes are inside the
+    // matrix -- one running pointer, eight plain loads per chunk
+    auto group = [&](auto fast_tag, int64_t i0, bool more) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const float *dp = D + (i0 + 16 * CH + 8 * h) * m + j;    // (dereferenced on the fast path only)
+        stage_load(more ? i0 + 16 * CH : i0);                    // (unconditional: the last group is staged again, unread)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            u4v a[3];
+            split8(ring[ch], a);
+            // the slot just consumed takes the chunk one group ahead
+            if (FAST) {
+                const float *r = dp;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ring[ch][e] = *r; r += m; }
+                dp += 16 * m;
+            } else {
+                load_checked(ring[ch], i0 + 16 * (ch + CH));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u4v *src = &Ws[buf][ch * NP + (nt * 3) * 64 + lane];
+                u4v b[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) b[sp] = src[sp * 64];
+                ORIANA_MF6(acc[nt], a, b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_store(buf ^ 1);
+    };
+    for (int64_t i0 = ib; i0 < ie; i0 += 16 * CH) {
+        const bool more = i0 + 16 * CH < ie;
+        if (wave_fast && i0 + 32 * CH <= ie) group(std::true_type{}, i0, more);
+        else group(std::false_type{}, i0, more);
+        if (++groups == 16 / CH) {                               // 256 rows: leave the matrix core
+            groups = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { accs[nt][v] += acc[nt][v]; acc[nt][v] = 0.f; }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int64_t jj = jw + acc_row(v, h);
+            const int k = nt * 32 + c;
+            if (jj < m && k < K) atomicAdd(&out[jj * K + k], (double)accs[nt][v] + (double)acc[nt][v]);
+        }
+}
+
+template <int NT>
+static int launch_dt_b16(double *out, const float *D, const double *W, float *scratch, int64_t n, int64_t m, int K,
+                         hipStream_t st) {
+    u4v *img = reinterpret_cast<u4v *>(scratch);
+    hipLaunchKernelGGL(k_split_rows<NT>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, img, W, n, K);
+    const int64_t jb = (m + 127) / 128;
+    const int64_t splits0 = pick_splits(jb, (n + 255) / 256);
+    int64_t ips = (n + splits0 - 1) / splits0;
+    ips = (ips + 63) / 64 * 64;                                  // whole staged groups
+    const int64_t splits = (n + ips - 1) / ips;
+    if (splits > 65535 || jb > 0x7fffffffLL || (n + 15) / 16 > 0x7fffffffLL) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_dt_times_factor_b16<NT>, dim3((unsigned)jb, (unsigned)splits), dim3(256), 0, st, out, D,
+                       (const u4v *)img, n, m, K, ips);
+    return 0;
+}
+
 // scratch of oriana_dropout_sweep_fused (floats): logit(pi_d) [m rounded up to 64] | first images | second images
 static inline int64_t b16_img_floats(int64_t m, int pieces) { return ((m + 31) / 32) * (int64_t)pieces * 4; }
 
@@ -946,19 +1094,31 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
     return 0;
 }
 
-extern "C" int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, int64_t n, int64_t m,
-                                               int64_t K, void *stream) {
+extern "C" int64_t oriana_dense_t_scratch_floats(int64_t n, int64_t K) {
+    if (n < 0 || K < 0) return 0;
+    return ((n + 15) / 16 + 4) * (int64_t)(2 * 3 * 64) * 4;       // operand images of W at their largest (K <= 64)
+}
+
+extern "C" int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, float *scratch, int arithmetic,
+                                               int64_t n, int64_t m, int64_t K, void *stream) {
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (K > 128) return ORIANA_EKRANGE;
     if (n == 0 || m == 0) return 0;
     if (!out || !D || !W) return ORIANA_EINVAL;
+    if (arithmetic != ORIANA_MATRIX_F32 && arithmetic != ORIANA_MATRIX_BF16X3) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    switch ((int)((K + 31) / 32)) {
-        case 1: rc = launch_dt<1, 4>(out, D, W, n, m, (int)K, st); break;
-        case 2: rc = launch_dt<2, 2>(out, D, W, n, m, (int)K, st); break;
-        case 3: rc = launch_dt<3, 1>(out, D, W, n, m, (int)K, st); break;
-        default: rc = launch_dt<4, 1>(out, D, W, n, m, (int)K, st); break;
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
+        if (!scratch || ((uintptr_t)scratch & 15) != 0) return ORIANA_EINVAL;
+        if (K <= 32) rc = launch_dt_b16<1>(out, D, W, scratch, n, m, (int)K, st);
+        else rc = launch_dt_b16<2>(out, D, W, scratch, n, m, (int)K, st);
+    } else {
+        switch ((int)((K + 31) / 32)) {
+            case 1: rc = launch_dt<1, 4>(out, D, W, n, m, (int)K, st); break;
+            case 2: rc = launch_dt<2, 2>(out, D, W, n, m, (int)K, st); break;
+            case 3: rc = launch_dt<3, 1>(out, D, W, n, m, (int)K, st); break;
+            default: rc = launch_dt<4, 1>(out, D, W, n, m, (int)K, st); break;
+        }
     }
     if (rc) return rc;
     ORIANA_LAUNCH_CHECK();

@@ -51,6 +51,7 @@ class _ZIMixin:
         self.n_kept_products = 0          # sweeps whose D_hat V came from the previous sweep's D update
         from .. import _lib
         self._lg_scratch = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, self.k)), dtype=torch.float32, device=dev)
+        self._dt_scratch = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, self.k)), dtype=torch.float32, device=dev)
         # how the float32 products are evaluated (include/oriana_hip.h): 1 = three-way bf16 splits on the bf16 matrix
         # cores (K <= 64), 0 = the float32 matrix instruction
         self._matrix_arith = {'f32': 0, 'bf16x3': 1}[os.environ.get('ORIANA_ZI_MATRIX', 'bf16x3')]
@@ -108,8 +109,8 @@ class _ZIMixin:
         out = torch.zeros(self.m, self.k, dtype=torch.float64, device=self.device)
         with engine._span(self._ws, 'DtU'):
             if self._fast_dense:
-                call('oriana_dense_t_times_factor_f32', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m,
-                     self.k, stream_ptr())
+                call('oriana_dense_t_times_factor_f32', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), ptr(self._dt_scratch),
+                     self._matrix_arith, self.n, self.m, self.k, stream_ptr())
             else:
                 call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m,
                      self.k, 1, stream_ptr())

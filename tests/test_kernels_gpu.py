@@ -498,25 +498,31 @@ F32_SHAPES = [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 102
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,m,K', F32_SHAPES)
-def test_dense_t_times_factor_f32(n, m, K):
-    """D_hat^T U_hat (zigap.py:124) with float32 products and sums that end in float64, against the float64 product."""
+@pytest.mark.parametrize('arithmetic', [0, 1], ids=['f32', 'bf16x3'])
+def test_dense_t_times_factor_f32(n, m, K, arithmetic):
+    """D_hat^T U_hat (zigap.py:124) with float32 products (the float32 matrix instruction, or three-way bf16 splits on the
+    bf16 matrix cores for K <= 64) and sums that end in float64, against the float64 product."""
     import torch
+    from oriana_amd import _lib
     from oriana_amd._lib import call, ptr, stream_ptr
     g = torch.Generator(device='cpu').manual_seed(n * 7 + m * 3 + K)
     D = torch.rand(n, m, generator=g, dtype=torch.float32)
     D[D < 0.3] = 0.0
+    D[torch.rand(n, m, generator=g) < 0.05] *= 1e-6          # some tiny dropout probabilities
     W = torch.rand(n, K, generator=g, dtype=torch.float64) * 3.0
     Dd, Wd = D.cuda(), W.cuda()
     out = torch.zeros(m, K, dtype=torch.float64, device='cuda')
-    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(Dd), ptr(Wd), n, m, K, stream_ptr())
+    scr = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device='cuda')
+    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(Dd), ptr(Wd), ptr(scr), arithmetic, n, m, K, stream_ptr())
     torch.cuda.synchronize()
     ref = (D.double().t() @ W).numpy()
     # positive terms: relative error of the sums.  256-term float32 chains (3e-7 rms each) averaged over the chunks
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-30)
     if n >= 1000:
-        rel = np.abs(out.cpu().numpy() - ref) / np.maximum(ref, 1e-300)
+        rel = (out.cpu().numpy() - ref) / np.maximum(ref, 1e-300)
         assert np.sqrt(np.mean(rel ** 2)) < 2.5e-7
-    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(Dd), ptr(Wd), n, m, K, stream_ptr())     # accumulates
+        assert abs(np.mean(rel)) < 1e-7                        # no drift: the matrix-core sums are cut every 256 terms
+    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(Dd), ptr(Wd), ptr(scr), arithmetic, n, m, K, stream_ptr())   # accumulates
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), 2.0 * ref, rtol=1e-6, atol=1e-30)
 
@@ -569,8 +575,9 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next, arithmetic):
         ref = (D1.double() @ Vn).cpu().numpy()                            # the product of the D_hat it stored
         np.testing.assert_allclose(DV.cpu().numpy(), ref, rtol=1e-6, atol=1e-30)
         if m >= 1000:
-            rel = np.abs(DV.cpu().numpy() - ref) / np.maximum(ref, 1e-300)
+            rel = (DV.cpu().numpy() - ref) / np.maximum(ref, 1e-300)
             assert np.sqrt(np.mean(rel ** 2)) < 2.5e-7
+            assert abs(np.mean(rel)) < 1e-7
 
 
 @pytest.mark.gpu
@@ -581,7 +588,8 @@ def test_f32_dense_entries_reject_large_K():
     t = torch.zeros(4, device='cuda', dtype=torch.float64)
     f = torch.zeros(4, device='cuda', dtype=torch.float32)
     L = _lib.load()
-    assert L.oriana_dense_t_times_factor_f32(ptr(t), ptr(f), ptr(t), 1, 1, 129, None) == -2
+    assert L.oriana_dense_t_times_factor_f32(ptr(t), ptr(f), ptr(t), None, 0, 1, 1, 129, None) == -2
+    assert L.oriana_dense_t_times_factor_f32(ptr(t), ptr(f), ptr(t), None, 1, 1, 1, 3, None) == -1      # bf16x3 needs its scratch
     assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, ptr(f), 0, 1, 1, 129, None) == -2
     assert L.oriana_dropout_sweep_fused(ptr(f), ptr(t), ptr(t), ptr(t), None, None, None, None, ptr(f), 7, 1, 1, 1, None) == -1
 

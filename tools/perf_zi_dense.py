@@ -45,7 +45,11 @@ rows.append(('f32  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K 
 if '--shipped-only' not in sys.argv:       # (counter runs: only the two kernels a sweep launches)
     t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), None, None, ptr(lgs), 0, n, m, K, st))
     rows.append(('f32  D update alone', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
-t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), n, m, K, st))
+scr = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device=dev)
+if K <= 64:
+    t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), ptr(scr), 1, n, m, K, st))
+    rows.append(('bf16x3  D^T U', t, 2.0 * n * m * 32 * ((K + 31) // 32) / t / 1e9, 4.0 * n * m / t / 1e9))
+t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), ptr(scr), 0, n, m, K, st))
 rows.append(('f32  D^T U', t, 2.0 * n * m * 32 * ((K + 31) // 32) / t / 1e9, 4.0 * n * m / t / 1e9))
 if '--f64' in sys.argv:
     t = timeit(lambda: call('oriana_dropout_update_fused', None, ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), n, m, K, st))

@@ -226,7 +226,9 @@ def main():
                          'fixup_ms': ks.get('fixup', 0.0),
                          # the responsibility kernels are bound on the CU side: VALU issue + LDS-return
                          # traffic, not HBM -- the same launches against those rates
-                         'limiter': 'valu+lds (see DESIGN.md section 4)',
+                         'limiter': ('valu+lds (see DESIGN.md section 4)' if not model.zi else
+                                     'responsibility kernels: valu+lds (DESIGN.md section 4); dense ZI kernels: valu + matrix '
+                                     'cores, which barely overlap (DESIGN.md section 10h)'),
                          'valu': {'achieved': useful_tflops, 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': useful_tflops / VALU_PEAK_TFLOPS},
                          'lds': {'achieved': useful_lds_gbs, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',

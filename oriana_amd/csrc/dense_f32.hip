@@ -1,5 +1,7 @@
-// dense_f32.hip -- the dense (n x m) work of a zero-inflated SWEEP on the float32 matrix cores
-// (v_mfma_f32_32x32x2_f32, 2x the float64 rate), with every long sum carried in float64:
+// dense_f32.hip -- the dense (n x m) work of a zero-inflated SWEEP in float32 arithmetic on the matrix cores, with
+// every long sum carried on in float64.  Two evaluations of the same float32 products (`arithmetic`):
+//   ORIANA_MATRIX_BF16X3  three-way bf16 splits of each operand, six cross products on v_mfma_f32_32x32x16_bf16 (K <= 64)
+//   ORIANA_MATRIX_F32     v_mfma_f32_32x32x2_f32 (2x the float64 rate; K <= 128)
 //
 //   oriana_dropout_sweep_fused   D_hat = f32(sigmoid(logit(pi_d) - U_hat V_hat^T)) with the overrides of zigap.py:130-136,
 //                                the column sums of p_d, AND the product D_hat V_next of the NEXT sweep's cell-side

@@ -14,7 +14,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0]
-        if any(s in k for s in ('k_dropout_sweep', 'k_dt_times_factor_f32')):
+        if any(s in k for s in ('k_dropout_sweep', 'k_dt_times_factor')):
             k = k.split('::')[-1].split('<')[0]
             acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {k: {c: sum(v) / len(v) for c, v in dd.items()} for k, dd in acc.items()}

@@ -153,6 +153,15 @@ int oriana_row_pass(const oriana_counts *cm,
                     int32_t *tile_flag,     /* [nrb*ncb] out: 1 if the tile holds slow-path entries (zero it first) */
                     int64_t K, void *stream);
 
+/* The row pass of the sparse models with the S_hat-weighted sums folded in (sparse_gap.py:88-95): the dot product
+ * runs against FV (= exp-shifted E[log V] masked by S_tilde), the accumulation against FV2 (= FV * S_hat), both staged
+ * side by side in LDS -- R[i,:] = sum_j w_ij s_ij FV2[j,:] comes out of this pass and oriana_row_spmm is not needed.
+ * Returns ORIANA_EKRANGE when the two images of 256 factor rows do not fit (Kp > 64): use oriana_row_pass (with s_rs)
+ * followed by oriana_row_spmm then. */
+int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
+                           const float *w_nz, float *R, float *s_cs, float *sw_cs, int32_t *tile_flag, int64_t K,
+                           void *stream);
+
 /* R[i,:] = sum_j w_ij s_ij FV[j,:] with s given in row-side slots (sparse models: S_hat-weighted sums). */
 int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz,
                     const float *FV, float *R, int64_t K, void *stream);

@@ -366,15 +366,19 @@ struct WaveGeo {
 
 // ------------------------------------------------------------------------------------------
 // row pass:  s = x / <FU_i, FV_j>,   R_i += w s FV_j
-//   VAR bit 0: also write s in row-side slots (s_rs);  bit 1: per-entry weights w_nz / sw_cs
+//   VAR bit 0: sparse variant (masked factor rows), also writes s in row-side slots (s_rs);  bit 1: per-entry weights
+//   w_nz / sw_cs;  bit 2: sparse variant with a SECOND image FV2 (= FV * S_hat, sparse_gap.py:95): the dot product
+//   runs against FV, the accumulation against FV2 -- the S_hat-weighted row sums come out of this pass and the second
+//   row product (oriana_row_spmm over s_rs) disappears (K with both images in LDS: Kp <= 64)
 // ------------------------------------------------------------------------------------------
 template <int G, int T4, int TAIL, int VAR>
 __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float *__restrict__ FU,
                                                    const float *__restrict__ FV, const float *__restrict__ w_nz,
                                                    float *__restrict__ R, float *__restrict__ s_cs,
                                                    float *__restrict__ sw_cs, float *__restrict__ s_rs,
-                                                   int32_t *__restrict__ tile_flag) {
-    constexpr bool SROW = (VAR & 1) != 0, HASW = (VAR & 2) != 0;
+                                                   int32_t *__restrict__ tile_flag, const float *__restrict__ FV2) {
+    constexpr bool F2I = (VAR & 4) != 0;
+    constexpr bool SPARSE = (VAR & 5) != 0, SROW = (VAR & 1) != 0 && !F2I, HASW = (VAR & 2) != 0;
     constexpr int PD = HASW ? 2 : 3;            // prefetch depth (iterations), bounded by the register budget
     constexpr int KP = 4 * G * T4 + G * TAIL;   // TAIL: one extra float per lane after the float4 chunks
     constexpr int TOFF = 4 * G * T4;            // float offset of the tail inside a row
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
     // slow path even against a dead (fully masked, -0.0) gene row, whose skip is only certified for
     // ordinary rows.
     bool rowfilled = false;
-    if (SROW) {
+    if (SPARSE) {
         float fm = fut;
         #pragma unroll
         for (int t = 0; t < T4; ++t) fm = fmaxf(fmaxf(fmaxf(fu[t].x, fu[t].y), fmaxf(fu[t].z, fu[t].w)), fm);
@@ -447,10 +451,17 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                 rawq[d] = 0ull; wq[d] = 1.0f;
                 if (niter > 0) { rawq[d] = recp[(int64_t)id * 64]; if (HASW) wq[d] = w_nz[rbase + (int64_t)id * 64]; }
             }
-            Stage<KP4, TREP, CT> stg;
-            stg.load(FV, cb * TILE + csub * CT, cm.m, tid);
-            ORIANA_SYNC();                    // everybody is done with the previous image
-            stg.template store<STRIDE4>(lds, tid);
+            {
+                Stage<KP4, TREP, CT> stg;
+                stg.load(FV, cb * TILE + csub * CT, cm.m, tid);
+                ORIANA_SYNC();                // everybody is done with the previous image
+                stg.template store<STRIDE4>(lds, tid);
+            }
+            if (F2I) {
+                Stage<KP4, TREP, CT> stg2;
+                stg2.load(FV2, cb * TILE + csub * CT, cm.m, tid);
+                stg2.template store<STRIDE4>(lds + CT * STRIDE4, tid);
+            }
             ORIANA_SYNC();
             for (int it = 0; it < niter; ++it) {
                 uint32_t rx = (uint32_t)rawq[0], rm = (uint32_t)(rawq[0] >> 32);
@@ -485,13 +496,23 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                     const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;             \
                     const float sw = HASW ? s * qb_f32<U>(wcur) : s;                                  \
                     const f2 ss = {sw, sw};                                                           \
-                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
-                        acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);             \
-                        acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);             \
+                    if (F2I) {                /* accumulate against the second image */              \
+                        const f4 *vrow2 = vrow + CT * STRIDE4;                                        \
+                        _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                           \
+                            const f4 v2 = ORIANA_LDS_ROW(vrow2, choff[tt]);                           \
+                            acc[tt].xy = __builtin_elementwise_fma(ss, v2.xy, acc[tt].xy);            \
+                            acc[tt].zw = __builtin_elementwise_fma(ss, v2.zw, acc[tt].zw);            \
+                        }                                                                             \
+                        if (TAIL) acct = fmaf(sw, reinterpret_cast<const float *>(vrow2)[toff_lds], acct); \
+                    } else {                                                                          \
+                        _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                           \
+                            acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);         \
+                            acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);         \
+                        }                                                                             \
+                        if (TAIL) acct = fmaf(sw, vt, acct);                                          \
                     }                                                                                 \
-                    if (TAIL) acct = fmaf(sw, vt, acct);                                              \
                     /* fully masked gene (a -0.0 row): exactly zero contribution, no slow path */     \
-                    const bool dead = SROW && !rowfilled && den == 0.f &&                             \
+                    const bool dead = SPARSE && !rowfilled && den == 0.f &&                           \
                                       __float_as_uint(v[0].x) == 0x80000000u;                         \
                     const bool slow = valid && !ok && !dead; /* NaN = "evaluate me exactly" */       \
                     bad = bad || slow;                                                                \
@@ -1392,9 +1413,28 @@ static inline size_t lds_bytes(int G, int T4, int TAIL) {
 
 template <int G, int T4, int TAIL>
 static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
-                           float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s) {
+                           float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s,
+                           const float *FV2 = nullptr) {
     const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
+    if (FV2) {
+        // two images of 256 factor rows side by side: only where both fit (and the tile needs no column sub-tiles)
+        constexpr int KP = 4 * G * T4 + G * TAIL;
+        const size_t lb2 = 2 * lds_bytes(G, T4, TAIL);
+        if (use_k100(G, T4) || pick_nsub(KP) != 1 || lb2 > (size_t)LDS_BUDGET) return ORIANA_EKRANGE;
+        const dim3 grid2((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block2(1024);
+        if (w_nz) {
+            rc = set_lds(k_row_pass<G, T4, TAIL, 6>, lb2);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, 6>), grid2, block2, lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, FV2);
+        } else {
+            rc = set_lds(k_row_pass<G, T4, TAIL, 4>, lb2);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, 4>), grid2, block2, lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, FV2);
+        }
+        ORIANA_LAUNCH_CHECK();
+        return 0;
+    }
     if (use_k100(G, T4)) {
         constexpr int TL = (G == 4 && T4 == 6) ? TAIL : 0;
         const size_t lb2 = k100::image_bytes(TL);
@@ -1415,7 +1455,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
 #define ORIANA_RP(V)                                                                                  \
     rc = set_lds(k_row_pass<G, T4, TAIL, V>, lb);                                                           \
     if (rc) return rc;                                                                                \
-    hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
+    hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, (const float *)nullptr)
     if (var == 0) { ORIANA_RP(0); }
     else if (var == 1) { ORIANA_RP(1); }
     else if (var == 2) { ORIANA_RP(2); }
@@ -1571,6 +1611,23 @@ extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const f
     if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
 #define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s)
+    ORIANA_FOR_CFG(cfg, CALL);
+#undef CALL
+    return 0;
+}
+
+extern "C" int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
+                                      const float *w_nz, float *R, float *s_cs, float *sw_cs, int32_t *tile_flag,
+                                      int64_t K, void *stream) {
+    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
+    KCfg cfg;
+    if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
+    if (cm->n == 0) return 0;
+    if (!FU || !R || (cm->m > 0 && (!FV || !FV2)) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
+    if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
+    if (cm->m == 0) return oriana_row_pass(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, K, stream);
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, s, FV2)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;

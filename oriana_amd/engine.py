@@ -469,6 +469,10 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
          base, nbytes, stream_ptr())
 
 
+# ORIANA_SPARSE_ROWS=split keeps the two-kernel form of the sparse row phase (A/B runs)
+_FUSE_SPARSE_ROWS = os.environ.get('ORIANA_SPARSE_ROWS', 'fused') != 'split'
+
+
 def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None, w_nz=None, phase='all'):
     """The four loop nests on the resident tiles.  `w_nz` = D_hat at the stored entries (row-side
     slots, CountTiles.side_nz); None means 1, which is always the case inside the models
@@ -485,8 +489,6 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
     st = stream_ptr()
     if phase in ('all', 'rows'):
         _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
-        if sparse and ws.s_rs is None:
-            ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
         if w_nz is not None and ws.sw_cs is None:
             ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
     sw_cs = ws.sw_cs if w_nz is not None else None
@@ -495,17 +497,33 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         Z_i.zero_(); Z_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
         if Z_log is not None:
             Z_log.zero_()
-        with _span(ws, 'row_pass'):
-            call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
-                 ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
-        with _span(ws, 'fixup'):
-            call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs), ptr(ws.s_rs) if sparse else None,
-                 ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
-                 K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
-        R = ws.R
+        # sparse models: the S_hat-weighted row sums (sparse_gap.py:95).  Where two factor images fit in LDS (Kp <= 64)
+        # they come out of the row pass itself (dot product against FV, accumulation against FV * S_hat); otherwise the
+        # pass leaves s in row-side slots and a second row product follows.
+        fused = False
         if sparse:
             F2 = ws.extra('FVS', m)
             call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
+            if _FUSE_SPARSE_ROWS:
+                with _span(ws, 'row_pass'):
+                    rc = _lib.load().oriana_row_pass_masked(ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(F2), ptr(w_nz), ptr(ws.R),
+                                                            ptr(ws.s_cs), ptr(sw_cs), ptr(ws.tile_flag), K, st)
+                if rc not in (0, -2):
+                    raise _lib.OrianaHipError('oriana_row_pass_masked failed with code %d' % rc)
+                fused = rc == 0
+        if not fused:
+            if sparse and ws.s_rs is None:       # row-side copy of s for the second row product (lazy: the fused form never needs it)
+                ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
+            with _span(ws, 'row_pass'):
+                call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
+                     ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
+        with _span(ws, 'fixup'):
+            call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs),
+                 ptr(ws.s_rs) if (sparse and not fused) else None,
+                 ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
+                 K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
+        R = ws.R
+        if sparse and not fused:
             with _span(ws, 'row_spmm'):
                 call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), ptr(w_nz), ptr(F2), ptr(ws.R), K, st)
         call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(R), None, ptr(ct.row_perm), n, K, 1, st)

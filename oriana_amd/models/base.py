@@ -138,7 +138,7 @@ class FactorModel:
         self._Zj = self._xch.f32['Zj']
         self._sumU = torch.zeros(2, K, **f64)        # [sum_i U_hat, sum_i log_U_hat]
         self._sumV = torch.zeros(2, K, **f64)
-        self._ws = engine.ZWorkspace(self.counts, K, need_sw=False, need_srow=self.sparse)
+        self._ws = engine.ZWorkspace(self.counts, K, need_sw=False, need_srow=False)     # (s_rs: allocated on first use)
         self._init_extra()
         self.U = _Buffer(lambda: self._U_hat)
         self.V = _Buffer(lambda: self._effective_V())

@@ -342,6 +342,47 @@ def test_zq_sparse_random(eng, K):
     assert not Zj.cpu().numpy()[5].any()
 
 
+@pytest.mark.parametrize('K,weighted', [(3, False), (20, True), (50, False), (64, True), (64, False), (70, False)])
+def test_sparse_row_phase_fused_matches_split(eng, K, weighted, monkeypatch):
+    """The sparse row phase with the S_hat-weighted sums folded into the row pass (two factor images in LDS, Kp <= 64)
+    against the two-kernel form (row pass + row product over the stored s), and both against the oracle; with slow-path
+    entries and a dead gene; K = 70 does not fit two images and takes the two-kernel form in both runs."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(K + 17)
+    n, m = 700, 530
+    X = _rand_counts(rng, n, m, 0.12)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    lu[3] -= 80.0                               # a cell whose entries take the exact slow path
+    ps = rng.random((m, K))
+    St = (ps > 0.3).astype(np.float32); Sh = ps.astype(np.float32)
+    St[7] = 0                                   # a gene with every factor switched off
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    c = lambda v: torch.from_numpy(v).cuda()
+    D = rng.random((n, m)).astype(np.float32) if weighted else None
+    w_nz = None
+    if weighted:
+        ct = eng.CountTiles.from_dense(X, 'cuda', side=c(D))
+        w_nz = ct.side_nz
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setattr(eng, '_FUSE_SPARSE_ROWS', mode)
+        ws = eng.ZWorkspace(ct, K)
+        Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda'); Zl = torch.empty(m, K, device='cuda')
+        eng.zq(ws, Zi, Zj, Zl, c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh), w_nz=w_nz)
+        out[mode] = [t.cpu().numpy() for t in (Zi, Zj, Zl)]
+        assert (ws.s_rs is None) == (mode and K <= 64)      # the fused form never needs the row-side copy of s
+    for a, b in zip(out[True], out[False]):
+        assert err_colrel(a, b) < 2e-6
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    Xf = np.ascontiguousarray(X.astype(np.float32))
+    if weighted:
+        co.zq_sparse_zigap(r[0], r[1], r[2], lu, lv, St, Sh, D, Xf)
+    else:
+        co.zq_sparse_gap(r[0], r[1], r[2], lu, lv, St, Sh, Xf)
+    for got, ref in zip(out[True], r):
+        assert err_colrel(got, ref) < RTOL
+
+
 @pytest.mark.parametrize('name', ['ZIGaP', 'SparseGaP', 'SparseZIGaP'])
 def test_variant_dropins_general_D(eng, name):
     """Model.compute_Z_q_expectations(...) with the reference's argument order on dense device

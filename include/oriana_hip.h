@@ -177,6 +177,12 @@ int oriana_col_pass(const oriana_counts *cm, const float *s_cs,
                     const int32_t *work, int64_t nwork,
                     void *stream);
 
+/* Two products over ONE walk of the column-side stream: C1 += s G1 and C2 += s G2 (the sparse models' per-gene sums
+ * and log sums, sparse_gap.py:96-97), both images of a row block side by side in LDS.  `work`: items
+ * (column TILE, first row block, end row block) -- one tile per item, whatever oriana_col_block_tiles(K) says.
+ * Returns ORIANA_EKRANGE when two images do not fit (Kp > 64): call oriana_col_pass twice then. */
+int oriana_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,
+                         float *C2, int64_t K, const int32_t *work, int64_t nwork, void *stream);
 /* Deterministic debug mode of the column pass (no counterpart in the reference, which is
  * single-threaded): every work item stores its accumulators in its own slab of `scratch`
  * (oriana_col_pass_det_scratch_bytes(K, nwork) bytes) instead of adding them to C with float atomics, and a

@@ -1211,13 +1211,19 @@ struct ColImage {
     }
 };
 
-template <int T4, int TAIL>
+// DUAL: ONE column tile per work item and TWO images (Gm, Gm2) of the row block side by side in LDS: both products
+// C += s Gm and C2 += s Gm2 from one walk over the slice's stream (the sparse models' per-gene sums and log sums,
+// sparse_gap.py:96-97; Kp <= 64: two images fit).
+template <int T4, int TAIL, bool DUAL>
 __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const float *__restrict__ s_cs,
                                                     const float *__restrict__ Gm, float *__restrict__ C,
                                                     const int32_t *__restrict__ work, int64_t rb_per_band,
-                                                    float *__restrict__ Cpart) {
+                                                    float *__restrict__ Cpart, const float *__restrict__ Gm2,
+                                                    float *__restrict__ C2) {
     using Im = ColImage<T4, TAIL>;
+    static_assert(!(DUAL && Im::DUP), "two duplicated images do not fit");
     constexpr int KP = Im::KP, ROW4 = Im::ROW4;
+    constexpr int IMG4 = TILE * ROW4;                             // float4 per image
     constexpr int CPD = 3;
     extern __shared__ f4 lds[];
     const float *tails = reinterpret_cast<const float *>(lds) + Im::TBASE;
@@ -1232,8 +1238,8 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
         rb0 = (int64_t)blockIdx.y * rb_per_band;
         rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
     }
-    const int64_t cbA = c2 * 2, cbB = c2 * 2 + 1;
-    const bool hasB = cbB < cm.ncb;
+    const int64_t cbA = DUAL ? c2 : c2 * 2, cbB = DUAL ? c2 : c2 * 2 + 1;
+    const bool hasB = !DUAL && cbB < cm.ncb;
     const int toff = Im::toff(lane);
     int lidx[T4];
     #pragma unroll
@@ -1279,6 +1285,42 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
                     _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(ACC[tt]));  \
                     asm volatile("" : "+v"(svc), "+v"(rvc));                                          \
                 }
+#define ORIANA_COL_STEP4D(U)                                                                          \
+                {                                                                                     \
+                    const float s = qb_f32<U>(svc);                                                   \
+                    const int r = (int)qb_u32<U>(rvc);                                                \
+                    const f4 *vrow = lds + r * ROW4;                                                  \
+                    const f2 ss = {s, s};                                                             \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        const f4 v = vrow[lidx[tt]];                                                  \
+                        accA[tt].xy = __builtin_elementwise_fma(ss, v.xy, accA[tt].xy);               \
+                        accA[tt].zw = __builtin_elementwise_fma(ss, v.zw, accA[tt].zw);               \
+                        const f4 v2 = vrow[IMG4 + lidx[tt]];                                          \
+                        accB[tt].xy = __builtin_elementwise_fma(ss, v2.xy, accB[tt].xy);              \
+                        accB[tt].zw = __builtin_elementwise_fma(ss, v2.zw, accB[tt].zw);              \
+                    }                                                                                 \
+                    if (TAIL) {                                                                       \
+                        actA = fmaf(s, tails[r * Im::TSTR + toff], actA);                             \
+                        actB = fmaf(s, tails[IMG4 * 4 + r * Im::TSTR + toff], actB);                  \
+                    }                                                                                 \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(accA[tt]), "+v"(accB[tt]));  \
+                    asm volatile("" : "+v"(svc), "+v"(rvc));                                          \
+                }
+#define ORIANA_COL_RUN4D(ST)                                                                          \
+            {                                                                                         \
+                const int last = (ST.nit > 0) ? ST.nit - 1 : 0;                                       \
+                for (int it = 0; it < ST.nit; ++it) {                                                 \
+                    float svc = ST.sv[0]; uint32_t rvc = ST.rv[0];                                    \
+                    _Pragma("unroll") for (int d = 0; d + 1 < CPD; ++d) { ST.sv[d] = ST.sv[d + 1]; ST.rv[d] = ST.rv[d + 1]; } \
+                    const int nx = (it + CPD < last) ? it + CPD : last;                               \
+                    ST.sv[CPD - 1] = ST.sb[nx * 64 + lane];                                           \
+                    ST.rv[CPD - 1] = ST.rb[nx * 64 + lane];                                           \
+                    ORIANA_COL_STEP4D(0)                                                              \
+                    ORIANA_COL_STEP4D(1)                                                              \
+                    ORIANA_COL_STEP4D(2)                                                              \
+                    ORIANA_COL_STEP4D(3)                                                              \
+                }                                                                                     \
+            }
 #define ORIANA_COL_RUN4(ST, ACC, ACT)                                                                 \
             {                                                                                         \
                 const int last = (ST.nit > 0) ? ST.nit - 1 : 0;                                       \
@@ -1297,26 +1339,40 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
     Stream stA, stB, stN;
     if (rb0 < rb1) open_stream(stA, rb0 * cm.ncb + cbA, true);
     for (int64_t rb = rb0; rb < rb1; ++rb) {
-        open_stream(stB, rb * cm.ncb + (hasB ? cbB : cbA), hasB);      // in flight during the first tile's loop
+        if (!DUAL) open_stream(stB, rb * cm.ncb + (hasB ? cbB : cbA), hasB);      // in flight during the first tile's loop
         if (Im::DUP) {
             k100::Stage<1024, TAIL> stg;
             stg.load(Gm, rb * TILE, cm.n, tid);
             ORIANA_SYNC();
             stg.store(lds, tid);
         } else {
-            Stage<Im::KP4, Im::TREP, TILE> stg;
-            stg.load(Gm, rb * TILE, cm.n, tid);
-            ORIANA_SYNC();
-            stg.template store<ROW4>(lds, tid);
+            {
+                Stage<Im::KP4, Im::TREP, TILE> stg;
+                stg.load(Gm, rb * TILE, cm.n, tid);
+                ORIANA_SYNC();
+                stg.template store<ROW4>(lds, tid);
+            }
+            if (DUAL) {
+                Stage<Im::KP4, Im::TREP, TILE> stg2;
+                stg2.load(Gm2, rb * TILE, cm.n, tid);
+                stg2.template store<ROW4>(lds + IMG4, tid);
+            }
         }
         ORIANA_SYNC();
-        ORIANA_COL_RUN4(stA, accA, actA)
-        // the next row block's first stream is requested before the second tile's loop: its (HBM) latency is
-        // hidden behind that loop instead of being paid between two images
-        if (rb + 1 < rb1) open_stream(stN, (rb + 1) * cm.ncb + cbA, true);
-        ORIANA_COL_RUN4(stB, accB, actB)
+        if (DUAL) {
+            if (rb + 1 < rb1) open_stream(stN, (rb + 1) * cm.ncb + cbA, true);   // the next row block's stream, in flight
+            ORIANA_COL_RUN4D(stA)
+        } else {
+            ORIANA_COL_RUN4(stA, accA, actA)
+            // the next row block's first stream is requested before the second tile's loop: its (HBM) latency is
+            // hidden behind that loop instead of being paid between two images
+            if (rb + 1 < rb1) open_stream(stN, (rb + 1) * cm.ncb + cbA, true);
+            ORIANA_COL_RUN4(stB, accB, actB)
+        }
         stA = stN;
     }
+#undef ORIANA_COL_RUN4D
+#undef ORIANA_COL_STEP4D
 #undef ORIANA_COL_RUN4
 #undef ORIANA_COL_STEP4
     const int cl = sl * 16 + (lane >> 2);
@@ -1327,17 +1383,17 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
         // one tile at a time through LDS (256 x Kp floats), then a contiguous flush (see flush_block)
         const int64_t c0 = (h ? cbB : cbA) * TILE;
         ORIANA_SYNC();
-        if ((h == 0 || hasB) && c0 + cl < cm.m) {
+        if ((h == 0 || hasB || DUAL) && c0 + cl < cm.m) {
             float *row = ldsf + cl * KP;
             #pragma unroll
             for (int t = 0; t < T4; ++t) *reinterpret_cast<f4 *>(row + Im::gidx(lane, t) * 4) = h ? accB[t] : accA[t];
             if (TAIL) row[Im::TOFF + q] = h ? actB : actA;
         }
         ORIANA_SYNC();
-        if (h == 0 || hasB) {
+        if (h == 0 || hasB || DUAL) {
             const int64_t left = cm.m - c0;
             const int ncols = left < TILE ? (left > 0 ? (int)left : 0) : TILE;
-            float *dst = plain ? Cpart + ((int64_t)blockIdx.x * 2 * TILE + h * TILE) * KP : C + c0 * KP;
+            float *dst = plain ? Cpart + ((int64_t)blockIdx.x * 2 * TILE + h * TILE) * KP : ((DUAL && h) ? C2 : C) + c0 * KP;
             flush_block<1024>(ldsf, dst, ncols * KP, plain, tid);
         }
     }
@@ -1490,12 +1546,13 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const flo
         // work items / grid.x index PAIRS of column tiles (oriana_col_block_tiles = 2)
         constexpr int T4c = (G == 4) ? T4 : 1, TLc = (G == 4) ? TAIL : 0;       // (only instantiated for G = 4)
         const size_t lb2 = ColImage<T4c, TLc>::bytes();
-        auto kern = k_col_pass2<T4c, TLc>;
+        auto kern = k_col_pass2<T4c, TLc, false>;
         int rc2 = set_lds(kern, lb2);
         if (rc2) return rc2;
         if (work) {
             if (nwork <= 0) return 0;
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(1024), lb2, s, *cm, s_cs, Gm, C, work, (int64_t)0, Cpart);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(1024), lb2, s, *cm, s_cs, Gm, C, work, (int64_t)0, Cpart,
+                               (const float *)nullptr, (float *)nullptr);
         } else {
             const int64_t ncp = (cm->ncb + 1) / 2;
             int64_t nb = (1024 + ncp - 1) / ncp;
@@ -1506,7 +1563,7 @@ static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const flo
             const int64_t per = (cm->nrb + nb - 1) / nb;
             nb = (cm->nrb + per - 1) / per;
             hipLaunchKernelGGL(kern, dim3((unsigned)ncp, (unsigned)nb), dim3(1024), lb2, s, *cm, s_cs, Gm, C,
-                               (const int32_t *)nullptr, per, (float *)nullptr);
+                               (const int32_t *)nullptr, per, (float *)nullptr, (const float *)nullptr, (float *)nullptr);
         }
         ORIANA_LAUNCH_CHECK();
         return 0;
@@ -1657,6 +1714,39 @@ extern "C" int oriana_col_pass(const oriana_counts *cm, const float *s_cs, const
     hipStream_t s = (hipStream_t)stream;
     if (nwork < 0 || (work == nullptr && nwork != 0)) return ORIANA_EINVAL;
 #define CALL(G, T, L) return launch_col_pass<G, T, L>(cm, s_cs, Gm, C, work, nwork, (float *)nullptr, s)
+    ORIANA_FOR_CFG(cfg, CALL);
+#undef CALL
+    return 0;
+}
+
+// two images, one column tile per work item (work list of width 1)
+template <int G, int T4, int TAIL>
+static int launch_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,
+                                float *C2, const int32_t *work, int64_t nwork, hipStream_t s) {
+    constexpr int T4c = (G == 4) ? T4 : 1, TLc = (G == 4) ? TAIL : 0;
+    using Im = ColImage<T4c, TLc>;
+    if (G != 4 || Im::DUP || 2 * Im::bytes() > (size_t)LDS_BUDGET) return ORIANA_EKRANGE;
+    if (nwork <= 0) return 0;
+    constexpr bool OK = (G == 4) && !Im::DUP;
+    auto kern = k_col_pass2<T4c, OK ? TLc : 0, OK>;
+    const size_t lb = 2 * Im::bytes();
+    int rc = set_lds(kern, lb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(1024), lb, s, *cm, s_cs, G1, C1, work, (int64_t)0, (float *)nullptr,
+                       G2, C2);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2,
+                                    float *C1, float *C2, int64_t K, const int32_t *work, int64_t nwork, void *stream) {
+    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
+    KCfg cfg;
+    if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
+    if (cm->n == 0 || cm->m == 0) return 0;
+    if (!G1 || !G2 || !C1 || !C2 || !s_cs || !work || nwork < 0) return ORIANA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(G, T, L) return launch_col_pass_dual<G, T, L>(cm, s_cs, G1, G2, C1, C2, work, nwork, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;

@@ -164,7 +164,9 @@ class CountTiles:
 
     def col_work_for(self, K):
         """The work list matching the column tiles per work-group of the kernel that serves this K (cached)."""
-        width = int(_lib.load().oriana_col_block_tiles(int(K))) or 1
+        return self.col_work_width(int(_lib.load().oriana_col_block_tiles(int(K))) or 1)
+
+    def col_work_width(self, width):
         if width not in self._col_work:
             self._col_work[width] = self._build_col_work(width=width)
         return self._col_work[width]
@@ -430,6 +432,21 @@ def col_pass(ct, s_cs, G, C, K):
     call('oriana_col_pass', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 
+def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K):
+    """C1 += s G1 and C2 += s G2 from one walk over the column-side stream (oriana_col_pass_dual).  Returns False when
+    the two factor images do not fit in LDS (or in the deterministic debug mode): the caller runs two column passes."""
+    if DETERMINISTIC or not _FUSE_SPARSE_COLS:
+        return False
+    w = ct.col_work_width(1)
+    if w is None:
+        return False
+    rc = _lib.load().oriana_col_pass_dual(ct.c_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1), ptr(C2), K, ptr(w), w.shape[0],
+                                          stream_ptr())
+    if rc not in (0, -2):
+        raise _lib.OrianaHipError('oriana_col_pass_dual failed with code %d' % rc)
+    return rc == 0
+
+
 def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
     """GaP.compute_Z_q_expectations (reference gap.py:67-80) on the resident tiles: outputs first,
     zero-filled by the callee, returns None.  `phase`: 'rows' stops once Z_hat_i is final (factor
@@ -471,6 +488,7 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
 
 # ORIANA_SPARSE_ROWS=split keeps the two-kernel form of the sparse row phase (A/B runs)
 _FUSE_SPARSE_ROWS = os.environ.get('ORIANA_SPARSE_ROWS', 'fused') != 'split'
+_FUSE_SPARSE_COLS = os.environ.get('ORIANA_SPARSE_COLS', 'fused') != 'split'
 
 
 def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None, w_nz=None, phase='all'):
@@ -538,20 +556,32 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
     if dq is not None:
         G, s_for_j = ws.extra('GQ', n), ws.s_cs
         call('oriana_scale_factor', ptr(G), ptr(ws.FU), ptr(dq), ptr(ct.row_perm), n, K, 0, st)
-    with _span(ws, 'col_pass'):
-        col_pass(ct, s_for_j, G, ws.C, K)
-    call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
+    # the log sums (zigap.py:95) need  sum_i s FU  and  sum_i s FU E[log U]  over the same stream: where two factor images
+    # fit in LDS both come from ONE column pass
+    dual_done = False
     if Z_log is not None:
         _check_f32(Z_log, (m, K))
         s_log = sw_cs if sw_cs is not None else ws.s_cs
-        if dq is not None:                      # the log sums use the D_hat[i, j]-weighted column sums
-            ws.C.zero_()
-            col_pass(ct, s_log, ws.FU, ws.C, K)
         G2 = ws.extra('GL', n)
         C2 = ws.extra('C2', m)
         C2.zero_()
-        with _span(ws, 'col_pass_log'):
-            col_pass(ct, s_log, G2, C2, K)
+        if dq is None:                          # the per-gene sums and the log sums share factor and stream
+            with _span(ws, 'col_pass'):
+                dual_done = col_pass_dual(ct, s_log, ws.FU, G2, ws.C, C2, K)
+    if not dual_done:
+        with _span(ws, 'col_pass'):
+            col_pass(ct, s_for_j, G, ws.C, K)
+    call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
+    if Z_log is not None:
+        if dq is not None:                      # the log sums use the D_hat[i, j]-weighted column sums
+            ws.C.zero_()
+            with _span(ws, 'col_pass_log'):
+                dual_done = col_pass_dual(ct, s_log, ws.FU, G2, ws.C, C2, K)
+                if not dual_done:
+                    col_pass(ct, s_log, ws.FU, ws.C, K)
+        if not dual_done:
+            with _span(ws, 'col_pass_log'):
+                col_pass(ct, s_log, G2, C2, K)
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ptr(ct.col_perm), m, K, st)
 
 

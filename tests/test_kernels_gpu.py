@@ -344,9 +344,10 @@ def test_zq_sparse_random(eng, K):
 
 @pytest.mark.parametrize('K,weighted', [(3, False), (20, True), (50, False), (64, True), (64, False), (70, False)])
 def test_sparse_row_phase_fused_matches_split(eng, K, weighted, monkeypatch):
-    """The sparse row phase with the S_hat-weighted sums folded into the row pass (two factor images in LDS, Kp <= 64)
-    against the two-kernel form (row pass + row product over the stored s), and both against the oracle; with slow-path
-    entries and a dead gene; K = 70 does not fit two images and takes the two-kernel form in both runs."""
+    """The sparse loop nest with the S_hat-weighted row sums folded into the row pass and the two per-gene sums taken in
+    one column pass (two factor images in LDS, Kp <= 64) against the four-kernel form (row pass + row product over the
+    stored s, two column passes), and both against the oracle; with slow-path entries and a dead gene; K = 70 does not
+    fit two images and takes the four-kernel form in both runs."""
     from oracle import cavi_oracle as co
     rng = np.random.default_rng(K + 17)
     n, m = 700, 530
@@ -366,6 +367,7 @@ def test_sparse_row_phase_fused_matches_split(eng, K, weighted, monkeypatch):
     out = {}
     for mode in (True, False):
         monkeypatch.setattr(eng, '_FUSE_SPARSE_ROWS', mode)
+        monkeypatch.setattr(eng, '_FUSE_SPARSE_COLS', mode)     # (same for the two per-gene sums: one column pass / two)
         ws = eng.ZWorkspace(ct, K)
         Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda'); Zl = torch.empty(m, K, device='cuda')
         eng.zq(ws, Zi, Zj, Zl, c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh), w_nz=w_nz)

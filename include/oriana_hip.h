@@ -146,7 +146,7 @@ int oriana_row_pass(const oriana_counts *cm,
                     const float *FU,        /* (n, Kp) */
                     const float *FV,        /* (m, Kp) */
                     const float *w_nz,      /* [rslots] per-entry weight (D_hat at the non-zeros) or NULL = 1 */
-                    float *R,               /* (n, Kp) out */
+                    float *R,               /* (n, Kp) out -- left untouched when s_rs is given (the pass then only produces s) */
                     float *s_cs,            /* [cslots] out: s_ij (unweighted), column-side slots; padding slots must hold 0 */
                     float *sw_cs,           /* [cslots] out: w_ij s_ij (required iff w_nz) */
                     float *s_rs,            /* [rslots] out: s_ij, row-side slots, or NULL */

@@ -366,7 +366,8 @@ struct WaveGeo {
 
 // ------------------------------------------------------------------------------------------
 // row pass:  s = x / <FU_i, FV_j>,   R_i += w s FV_j
-//   VAR bit 0: sparse variant (masked factor rows), also writes s in row-side slots (s_rs);  bit 1: per-entry weights
+//   VAR bit 0: sparse variant (masked factor rows), writes s in row-side slots (s_rs) INSTEAD of forming R (the caller
+//   follows with a row product over s_rs -- sparse models with Kp > 64, NMF start, metrics);  bit 1: per-entry weights
 //   w_nz / sw_cs;  bit 2: sparse variant with a SECOND image FV2 (= FV * S_hat, sparse_gap.py:95): the dot product
 //   runs against FV, the accumulation against FV2 -- the S_hat-weighted row sums come out of this pass and the second
 //   row product (oriana_row_spmm over s_rs) disappears (K with both images in LDS: Kp <= 64)
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                             acc[tt].zw = __builtin_elementwise_fma(ss, v2.zw, acc[tt].zw);            \
                         }                                                                             \
                         if (TAIL) acct = fmaf(sw, reinterpret_cast<const float *>(vrow2)[toff_lds], acct); \
-                    } else {                                                                          \
+                    } else if (!SROW) {       /* (with s_rs the caller only wants s: R is not formed) */ \
                         _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                           \
                             acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);         \
                             acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);         \
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
         }
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
-    if (row < cm.n) {
+    if (row < cm.n && !SROW) {
         #pragma unroll
         for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + choff[t]] = acc[t];
         if (TAIL) R[row * KP + TOFF + q] = acct;
@@ -1135,11 +1136,13 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
                 const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;                 \
                 const float sw = HASW ? s * pb_f32<U>((U & 1) ? wcur.y : wcur.x) : s;                 \
                 const f2 ss = {sw, sw};                                                               \
-                _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                                   \
-                    acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);                 \
-                    acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);                 \
+                if (!SROW) {                  /* (with s_rs the caller only wants s: R is not formed) */ \
+                    _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
+                        acc[tt].xy = __builtin_elementwise_fma(ss, v[tt].xy, acc[tt].xy);             \
+                        acc[tt].zw = __builtin_elementwise_fma(ss, v[tt].zw, acc[tt].zw);             \
+                    }                                                                                 \
+                    if (TAIL) acct = __builtin_elementwise_fma(ss, vt, acct);                         \
                 }                                                                                     \
-                if (TAIL) acct = __builtin_elementwise_fma(ss, vt, acct);                             \
                 const bool dead = SROW && !rowfilled && den == 0.f &&                                 \
                                   __float_as_uint(v[0].x) == 0x80000000u;                             \
                 const bool slow = valid && !ok && !dead;                                              \
@@ -1161,7 +1164,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         }
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
-    if (row < cm.n) {
+    if (row < cm.n && !SROW) {
         #pragma unroll
         for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + gchunk(lane, t)] = acc[t];
         if (TAIL) *reinterpret_cast<f2 *>(R + row * KP + 96 + 2 * q) = acct;

@@ -624,6 +624,40 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next, arithmetic):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('arithmetic', [0, 1], ids=['f32', 'bf16x3'])
+def test_dense_sweep_entries_wide_dynamic_range(arithmetic):
+    """Operands spread over 15 decades (Gamma means after many sweeps: a few dominant factors, the rest at the
+    1e-15 clamp): the three-way bf16 split keeps the float32 exponent range, so both arithmetics stay at float32
+    accuracy on every sum."""
+    import torch
+    from oriana_amd import _lib
+    from oriana_amd._lib import call, ptr, stream_ptr
+    n, m, K = 1500, 1100, 50
+    g = torch.Generator(device='cpu').manual_seed(5)
+    def logu(shape, lo, hi):
+        return torch.exp(torch.rand(shape, generator=g, dtype=torch.float64) * (np.log(hi) - np.log(lo)) + np.log(lo))
+    U = logu((n, K), 1e-15, 3.0).cuda(); V = logu((m, K), 1e-15, 3.0).cuda(); Vn = logu((m, K), 1e-12, 1e3).cuda()
+    pi = torch.rand(m, generator=g, dtype=torch.float64).cuda()
+    D1 = torch.empty(n, m, dtype=torch.float32, device='cuda'); D2 = torch.empty_like(D1)
+    cs = torch.zeros(m, dtype=torch.float64, device='cuda')
+    DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
+    scr = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
+    call('oriana_dropout_sweep_fused', ptr(D1), ptr(U), ptr(V), ptr(pi), None, ptr(cs), ptr(Vn), ptr(DV), ptr(scr), arithmetic,
+         n, m, K, stream_ptr())
+    call('oriana_dropout_update_fused', None, ptr(D2), ptr(U), ptr(V), ptr(pi), None, None, n, m, K, stream_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(D1.cpu().numpy(), D2.cpu().numpy(), rtol=2e-5, atol=3e-7)
+    ref = (D1.double() @ Vn).cpu().numpy()
+    np.testing.assert_allclose(DV.cpu().numpy(), ref, rtol=1e-6)
+    W = logu((n, K), 1e-15, 1e3).cuda()
+    out = torch.zeros(m, K, dtype=torch.float64, device='cuda')
+    s2 = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device='cuda')
+    call('oriana_dense_t_times_factor_f32', ptr(out), ptr(D1), ptr(W), ptr(s2), arithmetic, n, m, K, stream_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), (D1.double().t() @ W).cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_f32_dense_entries_reject_large_K():
     import torch
     from oriana_amd import _lib

@@ -4,7 +4,8 @@
 // different bank groups whatever their columns.  Measures ns per 16 slots per CU, to set against the shipped
 // four-lanes-per-row kernel (C5, K = 64: 29 ns; C3, K = 50: 32 ns per 16 slots per CU incl. staging and stores).
 //   MODE 0: full step (dot, rcp, accumulate, scattered store of s)   1: + second image for the accumulation
-//   ABL  0: full   1: no LDS reads   2: no FMAs
+//   ABL  0: full   1: no LDS reads   2: no FMAs   3: no scattered store of s   4: s through an LDS window, coalesced
+//        flush per tile (what a tile-local transposition of the s stream would cost)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -43,6 +44,10 @@ __global__ __launch_bounds__(512) void k(const u4 *__restrict__ rec, const float
     for (int it = 0; it < iters; ++it) {
         if (it % tile_it == 0) {                                  // restage the image(s)
             __syncthreads();
+            if (ABL == 4 && it > 0) {                             // flush the tile's window of s, 16 bytes per lane
+                const f4 *w = lds + (MODE ? 2 : 1) * 256 * 16;
+                for (int idx = tid; idx < 8192 / 4; idx += 512) reinterpret_cast<f4 *>(sd)[idx] = w[idx];
+            }
             for (int idx = tid; idx < (MODE ? 2 : 1) * 256 * 16; idx += 512) lds[idx] = reinterpret_cast<const f4 *>(F)[(idx + it) & 0xFFFF];
             __syncthreads();
         }
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(512) void k(const u4 *__restrict__ rec, const float
                     acc[t].zw = __builtin_elementwise_fma(ss, w.zw, acc[t].zw);
                 }
             } else acc[U].x += s;
-            sd[bm & 0x1FFF] = s;
+            if (ABL == 4) reinterpret_cast<float *>(lds)[(MODE ? 2 : 1) * 256 * 16 * 4 + (bm & 0x1FFF)] = s;
+            else if (ABL != 3 || s == 12345.678f) sd[bm & 0x1FFF] = s;
 #pragma unroll
             for (int t = 0; t < 16; ++t) asm volatile("" : "+v"(acc[t]));
         }
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(512) void k(const u4 *__restrict__ rec, const float
 
 template <int MODE, int ABL> void run(const char *name, const u4 *rec, const float *F, float *sd, float *out) {
     const int blocks = 256, iters = 288, tile_it = 9;
-    const size_t lds = (MODE ? 2 : 1) * 256 * 16 * 16;
+    const size_t lds = (MODE ? 2 : 1) * 256 * 16 * 16 + (ABL == 4 ? 8192 * 4 : 0);
     (void)hipFuncSetAttribute((const void *)k<MODE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float ms = 0;
@@ -133,6 +139,8 @@ int main() {
     run<0, 0>("lane per row, K = 64: full, stage, store", rec, F, sd, out);
     run<0, 1>("  no LDS reads", rec, F, sd, out);
     run<0, 2>("  no FMAs", rec, F, sd, out);
+    run<0, 3>("  no scattered store", rec, F, sd, out);
+    run<0, 4>("  s through an LDS window, coalesced flush", rec, F, sd, out);
     run<1, 0>("lane per row, K = 64, second image", rec, F, sd, out);
     return 0;
 }

@@ -442,3 +442,24 @@ class FactorModel:
 
     def _load_extra(self, st):
         pass
+
+    def save(self, path):
+        """Checkpoint: the state of this rank (state(), plus the sweep count and the shapes) as one .npz file.  The
+        reference has no save / load; under row sharding every rank saves its own rows."""
+        st = self.state()
+        st['meta/n_sweeps'] = np.int64(self.n_sweeps)
+        st['meta/shape'] = np.asarray([self.n, self.m, self.k], dtype=np.int64)
+        st['meta/model'] = np.asarray(type(self).__name__)
+        np.savez(path, **st)
+
+    def restore(self, path):
+        """Load a checkpoint written by save() into this model (same class, same counts and k): the next step()
+        continues the run (the expectations are stored, nothing is recomputed)."""
+        with np.load(path, allow_pickle=False) as f:
+            shape = tuple(int(v) for v in f['meta/shape'])
+            if shape != (self.n, self.m, self.k) or str(f['meta/model']) != type(self).__name__:
+                raise ValueError('checkpoint of %s %s does not fit %s %s' % (str(f['meta/model']), shape, type(self).__name__,
+                                                                              (self.n, self.m, self.k)))
+            self.load_state({k: f[k] for k in f.files if not k.startswith('meta/')})
+            self.n_sweeps = int(f['meta/n_sweeps'])
+        return self

@@ -113,6 +113,30 @@ def test_zi_sweeps_float32_matrix_path_against_float64(path):
                        keys=['a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'p_d', 'pi_d', 'U_hat', 'V_hat'])
 
 
+@pytest.mark.parametrize('name', ['gap', 'zigap', 'sparsegap', 'sparsezigap'])
+def test_checkpoint_roundtrip(name, tmp_path):
+    """save() / restore(): a model restored from a checkpoint continues like the one that wrote it (two runs of the same
+    sweep differ by the order of their float atomics, 1e-7; the ZI models recompute one product in float64, 1e-6)."""
+    path = [f for f in _files() if os.path.basename(f).startswith(name + '_') and f.endswith('c1_rand.npz')][0]
+    g = load_golden(path)
+    A = _make(g)
+    A.fit(2)
+    ck = str(tmp_path / 'ck.npz')
+    A.save(ck)
+    B = _make(g)
+    B.restore(ck)
+    assert B.n_sweeps == 2
+    A.step(); B.step()
+    sa, sb = A.state(), B.state()
+    for k in sa:
+        d = np.max(np.abs(np.asarray(sa[k], np.float64) - np.asarray(sb[k], np.float64))) if np.size(sa[k]) else 0.0
+        assert err_colrel(sa[k], sb[k]) < 2e-6 or d < 2e-6, k
+    other = load_golden(os.path.join(os.path.dirname(path), name + ('_odd_rand.npz' if '_c1_' in path else '_c1_rand.npz')))
+    assert other['X'].shape != g['X'].shape
+    with pytest.raises(ValueError):
+        _make(other).restore(ck)
+
+
 def test_factors_and_attributes():
     g = load_golden(golden_files('gap_c1_rand.npz')[0])
     M = _make(g)

@@ -117,9 +117,10 @@ class FactorModel:
         # variational parameters (define_variational_distribution, gap.py:34-44)
         a1_0, b1_0, nmf = self._initial_shapes(X_host, init)
         self.nmf_factors = nmf
-        self.a1 = Parameter(a1_0.to(**f64).clamp_(min=1e-15).contiguous())       # gap.py:55
+        # (copy=True: a device tensor given as `init` must not become the parameter buffer of the model)
+        self.a1 = Parameter(a1_0.to(copy=True, **f64).clamp_(min=1e-15).contiguous())       # gap.py:55
         self.a2 = Parameter(torch.ones(n, K, **f64))
-        self.b1 = Parameter(b1_0.to(**f64).clamp_(min=1e-15).contiguous())       # gap.py:65
+        self.b1 = Parameter(b1_0.to(copy=True, **f64).clamp_(min=1e-15).contiguous())       # gap.py:65
         self.b2 = Parameter(torch.ones(m, K, **f64))
         # expectations (device); exposed as NumPy through the properties below
         self._U_hat = torch.empty(n, K, **f64)

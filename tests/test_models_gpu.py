@@ -583,6 +583,64 @@ def test_config5_sparse_full_size():
     torch.cuda.empty_cache()
 
 
+def test_init_tensors_are_not_aliased():
+    """A device tensor passed as init=(a1, b1) stays the caller's: two models built from the same tensors start alike."""
+    from oriana_amd.models import GaP
+    rng = np.random.default_rng(3)
+    X = (rng.poisson(2.0, size=(300, 200)) * (rng.random((300, 200)) < 0.3)).astype(np.int64)
+    a1 = torch.from_numpy(rng.gamma(1.0, size=(300, 4))).cuda(); b1 = torch.from_numpy(rng.gamma(1.0, size=(200, 4))).cuda()
+    a1_0, b1_0 = a1.clone(), b1.clone()
+    A = GaP(X, k=4, init=(a1, b1), device='cuda')
+    A.fit(2)
+    assert torch.equal(a1, a1_0) and torch.equal(b1, b1_0)
+    B = GaP(X, k=4, init=(a1, b1), device='cuda')
+    B.fit(2)
+    assert err_colrel(A.state()['a1'], B.state()['a1']) < 1e-6
+
+
+def test_sparse_zi_at_config3_shape_against_float64_kernels():
+    """Sparse ZI-pCMF at the shape of BASELINE configs[2] (100,000 x 20,000, K = 50): three sweeps on the default path
+    (bf16 x 3 matrix kernels with V_next = S_hat * Vprime_hat != V, fused sparse row pass, the two per-gene sums in one
+    column pass) against the same model on the float64 matrix kernels and the four-kernel loop nest."""
+    from oriana_amd import engine
+    from oriana_amd.models import SparseZIGaP
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K = 100000, 20000, 50
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip('needs ~30 GB of free HBM')
+    gen = SyntheticCounts(n, m, K, seed=9234, device='cuda', zero_inflation_level=0.1)
+    ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, 'cuda')
+    a1, b1 = gen.initial_shapes()
+    fast = SparseZIGaP(ct, k=K, init=(a1, b1), device='cuda')
+    fast.fit(3)
+    assert fast.n_kept_products == 2 and fast._ws.s_rs is None
+    fused = (engine._FUSE_SPARSE_ROWS, engine._FUSE_SPARSE_COLS)
+    try:
+        engine._FUSE_SPARSE_ROWS = engine._FUSE_SPARSE_COLS = False
+        exact = SparseZIGaP(ct, k=K, init=(a1, b1), device='cuda')
+        exact._fast_dense = False
+        exact.fit(3)
+    finally:
+        engine._FUSE_SPARSE_ROWS, engine._FUSE_SPARSE_COLS = fused
+    assert exact.n_kept_products == 0 and exact._ws.s_rs is not None
+    # the cell side sees the gene side only through sums over 20,000 genes; the gene side carries S_hat, whose
+    # posterior p_s = sigmoid(logit(pi_s) - t), t a float32 difference of sums of magnitude 1e5..1e6, moves by up to
+    # 1e-2 under ANY change of the float32 summation order (helpers.sparsity_tolerance): measured 9e-3 on p_s, 3e-3 on
+    # b2 = beta2 + S_hat * (D_hat^T U_hat) between the two runs -- tight bound on the cell side, loose one on b1, b2
+    for name, tol in (('a1', 5e-6), ('a2', 5e-6), ('alpha1', 5e-6), ('alpha2', 5e-6), ('pi_d', 5e-6),
+                      ('b1', 1e-3), ('b2', 2e-2), ('beta1', 1e-5), ('beta2', 1e-5)):
+        a, b = getattr(fast, name).tensor, getattr(exact, name).tensor
+        assert torch.isfinite(a).all(), name
+        scale = b.abs().amax(dim=0, keepdim=True) if b.dim() == 2 else b.abs().max()
+        assert float(((a - b).abs() / (b.abs() + scale)).max()) < tol, name
+    # p_s is conditioning-limited (helpers.sparsity_tolerance): the two runs still agree far inside 1e-3 on average
+    assert float((fast.p_s.tensor - exact.p_s.tensor).abs().mean()) < 1e-3
+    assert float((fast._D_hat - exact._D_hat).abs().max()) < 5e-6
+    del fast, exact, ct
+    torch.cuda.empty_cache()
+
+
 def test_graph_replay_matches_eager():
     """A sweep captured in a hipGraph and replayed gives the eager sweeps' state."""
     g = load_golden(golden_files('gap_c1_rand.npz')[0])

@@ -193,6 +193,29 @@ def test_oracle_agreement_multi_tile(name):
                            ps_tol=sparsity_tolerance(O) if O.sparse else None)
 
 
+@pytest.mark.parametrize('K', [1, 33, 64, 65, 100, 128, 129])
+@pytest.mark.parametrize('name', ['ZIGaP', 'SparseZIGaP'])
+def test_zi_models_across_matrix_kernel_boundaries(name, K):
+    """The ZI sweeps at the K where the dense kernels change: bf16 x 3 up to 64, the float32 matrix instruction up to
+    128, the float64 kernels above; the fused sparse passes up to 64.  Three HIP sweeps (the second and third use the
+    product kept by the previous D update), each against the oracle sweep started from the same state."""
+    import oriana_amd.models as M
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(K)
+    n, m = 300, 270
+    X = (rng.poisson(3.0, size=(n, m)) * (rng.random((n, m)) < 0.25)).astype(np.int64)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    G = getattr(M, name)(X, k=K, init=(a1, b1))
+    O = co.MODELS[name](X, K, a1, b1)
+    for it in range(3):
+        O.load_state(G.state())
+        O.D_hat = G.D_hat.copy()                     # the float32 expectations the HIP sweep starts from
+        G.step(); O.step()
+        assert_state_close(G.state(), O.state(), what='%s K=%d sweep %d' % (name, K, it),
+                           ps_tol=sparsity_tolerance(O) if O.sparse else None)
+    assert G.n_kept_products == (2 if K <= 128 else 0)
+
+
 def test_config2_full_size_properties():
     """BASELINE.json configs[1] (10k x 2k, K = 20) at full size: conservation properties of a
     sweep (responsibilities sum to the counts) and agreement of the responsibility sums with the

@@ -24,7 +24,7 @@
 #include "common.h"
 #include <type_traits>
 // Compile-time ablation switches for the measurements quoted in DESIGN.md (never set in the shipped build):
-// ORIANA_ABL32_NOSTORE / _NOSIG / _NOTRANS / _NOMFMA1 drop one ingredient of k_dropout_sweep.
+// ORIANA_ABL32_NOSTORE / _NOSIG / _NOTRANS drop one ingredient of k_dropout_sweep.
 
 namespace oriana {
 

@@ -238,6 +238,25 @@ def main():
             'parity_slab': slab,
             'check': check,
         }
+        # launch-bound sizes: the same sweep replayed from a captured hipGraph (after, and outside, the timed region; the
+        # headline `value` stays the eager figure).  Informative only: at configs[1] a sweep is ~30 launches of a few
+        # microseconds of work each.
+        if world == 1 and not model.zi and float(n_total) * m <= 1e8:
+            try:
+                model._ws.timer = None
+                model.capture_graph()
+                for _ in range(5):
+                    model.step()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                reps = max(20, args.steps)
+                for _ in range(reps):
+                    model.step()
+                torch.cuda.synchronize()
+                out['graph_replay_ms_per_step'] = (time.perf_counter() - tg) / reps * 1e3
+            except Exception as exc:                 # never let the extra figure break the bench line
+                out['graph_replay_ms_per_step'] = None
+                out['graph_replay_error'] = repr(exc)[:200]
         if world > 1:
             out['per_rank_ms'] = {'columns': ['row_pass', 'col_pass', 'pass'], 'ranks': per_rank}
             out['allreduce_ms'] = allreduce_ms

@@ -98,7 +98,8 @@ def test_zi_sweeps_float32_matrix_path_against_float64(path):
         sf, se = fast.state(), exact.state()
         for k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2', 'beta1', 'beta2', 'U_hat', 'V_hat'):
             # measured <= 3e-7 per sweep; free-running, so the bound grows with the sweep
-            assert err_colrel(sf[k], se[k]) < 1e-6 * sweep, (sweep, k, err_colrel(sf[k], se[k]))
+            # (sparse models: the gene side carries S_hat, whose posterior amplifies any float32 difference)
+            assert err_colrel(sf[k], se[k]) < (3e-6 if fast.sparse else 1e-6) * sweep, (sweep, k, err_colrel(sf[k], se[k]))
         assert float(np.max(np.abs(sf['p_d'] - se['p_d']))) < 2e-6 * sweep
         assert float(np.max(np.abs(sf['pi_d'] - se['pi_d']))) < 1e-7 * sweep
         assert float(np.max(np.abs(fast.D_hat - exact.D_hat))) < 1e-6 * sweep

@@ -192,6 +192,48 @@ int64_t oriana_col_pass_det_scratch_bytes(int64_t K, int64_t nwork);
 int oriana_col_pass_det(const oriana_counts *cm, const float *s_cs, const float *G, float *C, int64_t K,
                         const int32_t *work, int64_t nwork, float *scratch, void *stream);
 
+/* ---- the densest genes on the matrix cores (hybrid layout) --------------------------------------------------
+ * Same loop nest (oriana/models/gap.py:67-80), other evaluation: the first `gd` PACKED genes (the densest ones, a
+ * multiple of 32; the host picks them from a density threshold) are kept as a dense uint16 block instead of the
+ * sliced non-zero layout; the oriana_counts of a hybrid layout then covers the packed genes [gd, m) only (its
+ * col_perm, FV and C pointers are the full arrays advanced by gd rows).  Their share of the pass,
+ *     den = FU FV^T,  s = x / den,  R += S FV,  C += S^T FU,
+ * runs as matrix products on the bf16 matrix cores in float32-EQUIVALENT arithmetic: every float32 operand enters as
+ * its exact three-way bf16 split (24 bits), six cross products per term, float32 accumulation, no sum longer than one
+ * tile on the matrix core (csrc/dense_pass.hip; DESIGN.md section 7 has the measured error).  Entries whose
+ * denominator fails the test of the sparse side get the same NaN sentinel and the same exact slow path.
+ * Counts must be integers in [0, 65535) for a gene to be eligible (the host checks). */
+typedef struct {
+    int64_t n;             /* cells of this shard */
+    int64_t gd;            /* dense genes = packed columns [0, gd), multiple of 32 */
+    int64_t nct;           /* allocated cell tiles of 32 rows: 8 * ceil(n / 256) */
+    const uint16_t *x;     /* [nct][gd / 32][1024] counts, register order of the row kernel (dense_pass.hip) */
+} oriana_dense;
+
+/* 1 if the dense evaluation is compiled for this K (K <= 100). */
+int oriana_dense_supported(int64_t K);
+/* 16-byte pieces of one 32-row tile's operand image; side 0 = gene side (FV), 1 = cell side (FU). */
+int64_t oriana_dense_image_pieces(int64_t K, int side);
+/* Pack `rows` rows (a multiple of 32 unless they are the last ones) of the already column-permuted dense chunk X
+ * (columns [0, gd), leading dimension ldx, dtypes as oriana_pack_count) into cell tiles ct_first.. of xd. */
+int oriana_dense_pack(const void *X, int xdtype, int64_t rows, int64_t gd, int64_t ldx, int64_t ct_first,
+                      uint16_t *xd, void *stream);
+/* Split operand images of a padded (rows, Kp) factor matrix, one per tile of 32 rows: img holds
+ * ceil(rows / 32) * oriana_dense_image_pieces(K, side) * 16 bytes. */
+int oriana_dense_images(void *img, const float *F, int64_t rows, int64_t K, int side, void *stream);
+/* Row side: S (nct * gd/32 * 1024 floats, out) and R[i,:] += sum_j s_ij FV[j,:] over the dense genes (R must hold the
+ * sparse genes' sums or zeros; added with atomics when gene_splits > 1).  flag: [nct][gd / 32] out (every entry written:
+ * 1 where the tile of s holds sentinels). */
+int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
+                          int32_t *flag, int64_t K, int64_t gene_splits, void *stream);
+/* Gene side: C[j,:] += sum_i s_ij FU[i,:] for the dense genes (atomics: zero C first), imgU = the cell-side images. */
+int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, const float *S, float *C, int64_t K,
+                          int64_t cell_splits, void *stream);
+/* Exact slow path for the flagged tiles (adds to the dense outputs Z_hat_i, Z_hat_j; clears the sentinels in S). */
+int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, const float *logU, const float *logV,
+                       const int32_t *row_perm, const int32_t *col_perm, float *Z_hat_i, float *Z_hat_j, int64_t K,
+                       void *stream);
+
 /* Z[o,k] = (accumulate ? Z[o,k] : 0) + F[i,k] * R[i,k] (* mul[o,k] if mul), o = row_index ? row_index[i] : i
  * -- dense (r, K) out from padded (r, Kp) in. */
 int oriana_finalize(float *Z, const float *F, const float *R, const float *mul, const int32_t *row_index,

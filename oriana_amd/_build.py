@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'dense_mfma.hip', 'dense_f32.hip', 'metrics.hip', 'stateless.hip']
+SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'dense_mfma.hip', 'dense_f32.hip', 'dense_pass.hip', 'metrics.hip', 'stateless.hip']
 LIB = os.path.join(CSRC, 'liboriana_hip.so')
 ARCH = 'gfx950'
 

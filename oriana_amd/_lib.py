@@ -24,6 +24,11 @@ class OrianaCounts(ctypes.Structure):
                 ('rowrec', c_void_p), ('ridx', c_void_p), ('col_perm', c_void_p), ('row_perm', c_void_p)]
 
 
+class OrianaDense(ctypes.Structure):
+    """struct oriana_dense (include/oriana_hip.h)."""
+    _fields_ = [('n', c_int64), ('gd', c_int64), ('nct', c_int64), ('x', c_void_p)]
+
+
 _P = c_void_p
 _I = c_int64
 _SIGS = {
@@ -42,6 +47,13 @@ _SIGS = {
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_det_scratch_bytes': (c_int64, [_I, _I]),
     'oriana_col_pass_det': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P, _P]),
+    'oriana_dense_supported': (c_int, [_I]),
+    'oriana_dense_image_pieces': (c_int64, [_I, c_int]),
+    'oriana_dense_pack': (c_int, [_P, c_int, _I, _I, _I, _I, _P, _P]),
+    'oriana_dense_images': (c_int, [_P, _P, _I, _I, c_int, _P]),
+    'oriana_dense_row_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_dense_col_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _I, _I, _P]),
+    'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),
     'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _I, c_int, _P]),

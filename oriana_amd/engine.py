@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import OrianaCounts, call, ptr, stream_ptr
+from ._lib import OrianaCounts, OrianaDense, call, ptr, stream_ptr
 
 TILE = 256
 _XDTYPE = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.float64: 3}
@@ -37,11 +37,17 @@ class CountTiles:
     """The count matrix X of one row shard, resident in HBM in the tiled, sliced non-zero layout
     (struct oriana_counts).  Built once: X is constant across sweeps (reference gap.py:29-32)."""
 
-    def __init__(self, n, m, device):
+    def __init__(self, n, m, device, gd=0):
         self.n, self.m = int(n), int(m)
         self.device = torch.device(device)
+        # hybrid layout: the first gd packed genes (the densest, a multiple of 32) live in a dense uint16 block
+        # (self.dense, csrc/dense_pass.hip); the sliced non-zero layout below then covers the packed genes [gd, m)
+        self.gd = int(gd)
+        assert self.gd % 32 == 0 and 0 <= self.gd <= self.m
+        self.ms = self.m - self.gd
+        self.dense = DenseBlock(self.n, self.gd, self.device) if self.gd else None
         self.nrb = (self.n + TILE - 1) // TILE
-        self.ncb = (self.m + TILE - 1) // TILE
+        self.ncb = (self.ms + TILE - 1) // TILE
         nt = max(self.nrb * self.ncb, 1)
         i32 = dict(dtype=torch.int32, device=self.device)
         self.tile_nnz = torch.zeros(nt, **i32)
@@ -51,7 +57,7 @@ class CountTiles:
         self.cslice = torch.zeros(nt * 17, **i32)
         self.roff = self.coff = None
         self.rowrec = self.ridx = None
-        self.nnz = self.rslots = self.cslots = 0
+        self.nnz = self.nnz_sparse = self.rslots = self.cslots = 0
         self.col_perm = None      # int32 [m]: packed column c holds gene col_perm[c] (None = identity)
         self.row_perm = None      # int32 [n]: packed row r holds cell row_perm[r] (None = identity)
         self.sort_rows = False
@@ -67,6 +73,23 @@ class CountTiles:
         in the caller's gene order."""
         order = torch.argsort(col_nnz.to(self.device), descending=True, stable=True)
         self.col_perm = order.to(torch.int32).contiguous()
+
+    @staticmethod
+    def dense_order(col_nnz, n_total, bad, density):
+        """(gene order, gd) of a hybrid layout: genes whose share of non-zero cells is >= `density` and whose counts
+        are all integers in [0, 65535) (`bad`: per-gene number of entries that are not) come first, in decreasing
+        order of their non-zero count, cut to a multiple of 32; the rest follows in decreasing order."""
+        order = torch.argsort(col_nnz, descending=True, stable=True)
+        ok = (col_nnz.to(torch.float64) >= float(density) * max(int(n_total), 1)) & (bad == 0) & (col_nnz > 0)
+        ok_sorted = ok[order]
+        cand = order[ok_sorted]
+        gd = (int(cand.numel()) // 32) * 32
+        if gd == 0:
+            return order, 0
+        keep = torch.ones(order.numel(), dtype=torch.bool, device=order.device)
+        keep[cand[:gd]] = False
+        rest = order[keep[order]]
+        return torch.cat([cand[:gd], rest]), gd
 
     def _permute(self, chunk, r0=None, learn=False):
         """Apply the internal orderings to a dense row chunk: genes by col_perm; cells, inside the chunk,
@@ -93,9 +116,11 @@ class CountTiles:
     def count_chunk(self, chunk, r0):
         chunk = self._permute(chunk, r0, learn=True)
         assert r0 % TILE == 0 and chunk.is_contiguous() and chunk.shape[1] == self.m
-        call('oriana_pack_count', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.m, chunk.stride(0),
-             r0 // TILE, self.ncb, ptr(self.tile_nnz), ptr(self.tile_rslots), ptr(self.tile_cslots),
-             ptr(self.rslice), ptr(self.cslice), stream_ptr())
+        if self.ms == 0:
+            return
+        call('oriana_pack_count', ptr(chunk) + self.gd * chunk.element_size(), _XDTYPE[chunk.dtype], chunk.shape[0],
+             self.ms, chunk.stride(0), r0 // TILE, self.ncb, ptr(self.tile_nnz), ptr(self.tile_rslots),
+             ptr(self.tile_cslots), ptr(self.rslice), ptr(self.cslice), stream_ptr())
 
     def finish_count(self):
         nt = self.nrb * self.ncb
@@ -106,7 +131,8 @@ class CountTiles:
             self.roff[1:] = torch.cumsum(self.tile_rslots[:nt].to(torch.int64), dim=0)
             self.coff[1:] = torch.cumsum(self.tile_cslots[:nt].to(torch.int64), dim=0)
         tot = torch.stack([self.roff[-1], self.coff[-1], self.tile_nnz[:max(nt, 1)].to(torch.int64).sum()]).tolist()
-        self.rslots, self.cslots, self.nnz = int(tot[0]), int(tot[1]), int(tot[2]) if nt else 0
+        self.rslots, self.cslots, self.nnz_sparse = int(tot[0]), int(tot[1]), int(tot[2]) if nt else 0
+        self.nnz = self.nnz_sparse
         # padding slots are recognised by x == 0 / read row index 0: zero-fill before the fill pass
         self.rowrec = torch.zeros(max(self.rslots, 1), **i64)                                   # 8-byte records
         self.ridx = torch.zeros(max(self.cslots, 1), dtype=torch.uint8, device=self.device)
@@ -116,8 +142,14 @@ class CountTiles:
         if side is not None:
             side = self._permute(side, r0)
         assert r0 % TILE == 0 and chunk.is_contiguous()
-        call('oriana_pack_fill', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.m, chunk.stride(0),
-             r0 // TILE, self.ncb, ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
+        if self.dense is not None:
+            if side is not None:
+                raise _lib.OrianaHipError('a hybrid (dense-gene) layout carries no per-entry side matrix')
+            self.dense.pack_chunk(chunk, r0)
+        if self.ms == 0:
+            return
+        call('oriana_pack_fill', ptr(chunk) + self.gd * chunk.element_size(), _XDTYPE[chunk.dtype], chunk.shape[0], self.ms,
+             chunk.stride(0), r0 // TILE, self.ncb, ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
              ptr(self.rowrec), ptr(self.ridx), ptr(side), side.stride(0) if side is not None else 0, ptr(side_nz),
              stream_ptr())
 
@@ -174,31 +206,72 @@ class CountTiles:
     def finish(self):
         self._col_work = {}
         self.tile_rslots = self.tile_cslots = None
-        self._struct = OrianaCounts(self.n, self.m, self.nrb, self.ncb, self.nnz, self.rslots, self.cslots,
+        if self.gd and self.col_perm is None:
+            raise _lib.OrianaHipError('a hybrid layout needs an explicit gene order')
+        # the sliced layout of a hybrid matrix is the sub-matrix of the packed genes [gd, m): its gene order is the
+        # full one advanced by gd entries (so are the FV / C pointers the passes get, see zq_gap)
+        self._struct = OrianaCounts(self.n, self.ms, self.nrb, self.ncb, self.nnz_sparse, self.rslots, self.cslots,
                                     ptr(self.roff), ptr(self.coff), ptr(self.rslice), ptr(self.cslice),
-                                    ptr(self.rowrec), ptr(self.ridx), ptr(self.col_perm), ptr(self.row_perm))
+                                    ptr(self.rowrec), ptr(self.ridx),
+                                    (ptr(self.col_perm) + 4 * self.gd) if self.col_perm is not None else None,
+                                    ptr(self.row_perm))
+        self.nnz = self.nnz_sparse + (self.dense.nnz if self.dense is not None else 0)
         return self
+
+    @staticmethod
+    def _gene_stats(chunks, m, device, reduce_fn, dense_density, n_total):
+        """Per-gene non-zero counts over all row shards and, for a hybrid layout, the gene order and gd."""
+        cn = torch.zeros(m, dtype=torch.int64, device=device)
+        bad = torch.zeros(m, dtype=torch.int64, device=device) if dense_density else None
+        n_local = 0
+        for c in chunks():
+            cn += (c != 0).sum(0)
+            n_local += c.shape[0]
+            if bad is not None:
+                cf = c if c.dtype.is_floating_point else None
+                b = (c < 0) | (c >= 65535)
+                if cf is not None:
+                    b |= cf != torch.floor(cf)
+                bad += b.sum(0)
+        if reduce_fn is not None:
+            reduce_fn(cn)
+            if bad is not None:
+                reduce_fn(bad)
+        if not dense_density:
+            return cn, None, 0
+        if n_total is None:
+            nt = torch.tensor([n_local], dtype=torch.int64, device=device)
+            if reduce_fn is not None:
+                reduce_fn(nt)
+            n_total = int(nt.item())
+        order, gd = CountTiles.dense_order(cn, n_total, bad, dense_density)
+        return cn, order, gd
 
     @classmethod
     def from_dense(cls, X, device='cuda', chunk_bytes=1 << 30, side=None, sort_cols=True, reduce_fn=None,
-                   sort_rows=False):
+                   sort_rows=False, dense_density=None, n_total=None):
         """Pack a dense (n, m) matrix (NumPy or torch, host or device).  `side`: optional dense
         (n, m) float32 DEVICE matrix gathered at the non-zeros (returned as .side_nz, row-side
         slots).  `reduce_fn`: sums the per-gene counts over row shards (all-reduce) so that every
-        rank packs the genes in the same order."""
+        rank packs the genes in the same order.  `dense_density`: build a HYBRID layout -- genes expressed in at
+        least this share of the cells (of all shards: `n_total`) go to a dense block evaluated on the matrix cores
+        (csrc/dense_pass.hip; pCMF only, K with oriana_dense_supported)."""
         n, m = X.shape
-        self = cls(n, m, device)
-        self.sort_rows = bool(sort_rows)
+        dev = torch.device(device)
         if n == 0 or m == 0:
+            self = cls(n, m, device)
             self.finish_count()
             return self.finish()
         rows = max(TILE, (chunk_bytes // max(1, m * 8)) // TILE * TILE)
-        if sort_cols:
-            cn = torch.zeros(m, dtype=torch.int64, device=self.device)
-            for r0 in range(0, n, rows):
-                cn += (_as_device_chunk(X, r0, min(n, r0 + rows), self.device) != 0).sum(0)
-            if reduce_fn is not None:
-                reduce_fn(cn)
+        gd, order = 0, None
+        if sort_cols or dense_density:
+            cn, order, gd = cls._gene_stats(lambda: (_as_device_chunk(X, r0, min(n, r0 + rows), dev) for r0 in range(0, n, rows)),
+                                            m, dev, reduce_fn, dense_density if side is None else None, n_total)
+        self = cls(n, m, device, gd=gd)
+        self.sort_rows = bool(sort_rows)
+        if order is not None:
+            self.col_perm = order.to(torch.int32).contiguous()
+        elif sort_cols:
             self.set_col_order(cn)
         for r0 in range(0, n, rows):
             self.count_chunk(_as_device_chunk(X, r0, min(n, r0 + rows), self.device), r0)
@@ -212,18 +285,20 @@ class CountTiles:
         return self.finish()
 
     @classmethod
-    def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda', sort_cols=True, reduce_fn=None, sort_rows=False):
+    def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda', sort_cols=True, reduce_fn=None, sort_rows=False,
+                    dense_density=None, n_total=None):
         """Passes over `chunk_fn(r0, r1) -> dense device tensor` (deterministic generator):
-        per-gene counts (when sort_cols), tile counts, fill."""
+        per-gene counts (when sort_cols), tile counts, fill.  `dense_density`, `n_total`: as from_dense."""
         assert chunk_rows % TILE == 0
-        self = cls(n, m, device)
+        gd, order = 0, None
+        if (sort_cols or dense_density) and n > 0 and m > 0:
+            cn, order, gd = cls._gene_stats(lambda: (chunk_fn(r0, min(n, r0 + chunk_rows)) for r0 in range(0, n, chunk_rows)),
+                                            m, torch.device(device), reduce_fn, dense_density, n_total)
+        self = cls(n, m, device, gd=gd)
         self.sort_rows = bool(sort_rows)
-        if sort_cols:
-            cn = torch.zeros(m, dtype=torch.int64, device=self.device)
-            for r0 in range(0, n, chunk_rows):
-                cn += (chunk_fn(r0, min(n, r0 + chunk_rows)) != 0).sum(0)
-            if reduce_fn is not None:
-                reduce_fn(cn)
+        if order is not None:
+            self.col_perm = order.to(torch.int32).contiguous()
+        elif sort_cols and n > 0 and m > 0:
             self.set_col_order(cn)
         for r0 in range(0, n, chunk_rows):
             self.count_chunk(chunk_fn(r0, min(n, r0 + chunk_rows)).contiguous(), r0)
@@ -264,14 +339,24 @@ class CountTiles:
 
     @property
     def c_struct(self):
+        """struct oriana_counts of a PURE sliced layout (every consumer that knows nothing of dense genes)."""
+        if self.gd:
+            raise _lib.OrianaHipError('this count matrix has a hybrid layout (dense genes on the matrix cores): only the pCMF '
+                                      'responsibility pass and the count metrics read it; pack without dense_density for this use')
+        return ctypes.byref(self._struct)
+
+    @property
+    def sparse_struct(self):
+        """The sliced layout: the whole matrix, or the packed genes [gd, m) of a hybrid layout."""
         return ctypes.byref(self._struct)
 
     def bytes_resident(self):
-        return self.rslots * 8 + self.cslots + (self.nrb * self.ncb) * (2 * 17 * 4 + 2 * 8 + 4)
+        b = self.rslots * 8 + self.cslots + (self.nrb * self.ncb) * (2 * 17 * 4 + 2 * 8 + 4)
+        return b + (self.dense.x.numel() * 2 if self.dense is not None else 0)
 
     def slot_efficiency(self):
-        """(nnz / row-side slots, nnz / column-side slots): the share of lanes that carry a real entry."""
-        return (self.nnz / max(self.rslots, 1), self.nnz / max(self.cslots, 1))
+        """(nnz / row-side slots, nnz / column-side slots) of the sliced layout: the share of lanes that carry a real entry."""
+        return (self.nnz_sparse / max(self.rslots, 1), self.nnz_sparse / max(self.cslots, 1))
 
     # ---- debugging / tests ------------------------------------------------------------------
     _REC = np.dtype([('x', '<f4'), ('cdst', '<u2'), ('col', 'u1'), ('pad', 'u1')])
@@ -286,7 +371,7 @@ class CountTiles:
     def to_dense(self):
         """Rebuild the dense float32 matrix on the host (tests only)."""
         X = np.zeros((self.nrb * TILE, self.ncb * TILE), dtype=np.float32)
-        if self.nnz:
+        if self.nnz_sparse:
             h = self.host_arrays()
             for rb in range(self.nrb):
                 for cb in range(self.ncb):
@@ -300,7 +385,9 @@ class CountTiles:
                         rows = rb * TILE + sl * 16 + ((slot & 63) >> 2)
                         keep = seg['x'] != 0
                         X[rows[keep], cb * TILE + seg['col'][keep].astype(np.int64)] = seg['x'][keep]
-        X = X[:self.n, :self.m]
+        X = X[:self.n, :self.ms]
+        if self.dense is not None:
+            X = np.concatenate([self.dense.to_dense(), X], axis=1)
         if self.row_perm is not None:
             out = np.zeros_like(X)
             out[self.row_perm.cpu().numpy()] = X
@@ -310,6 +397,44 @@ class CountTiles:
             out[:, self.col_perm.cpu().numpy()] = X
             X = out
         return X
+
+
+class DenseBlock:
+    """The densest genes of a hybrid layout (struct oriana_dense): uint16 counts in 32 x 32 blocks, in the register
+    order of the matrix-core row kernel (csrc/dense_pass.hip)."""
+
+    def __init__(self, n, gd, device):
+        self.n, self.gd = int(n), int(gd)
+        self.ngt = self.gd // 32
+        self.nct = (self.n + TILE - 1) // TILE * 8          # allocated cell tiles (whole 256-row blocks)
+        self.x = torch.zeros(self.nct * self.ngt * 1024, dtype=torch.uint16, device=device)
+        self.nnz = 0
+        self._struct = OrianaDense(self.n, self.gd, self.nct, ptr(self.x))
+
+    def pack_chunk(self, chunk, r0):
+        assert r0 % 32 == 0
+        self.nnz += int(torch.count_nonzero(chunk[:, :self.gd]).item())
+        call('oriana_dense_pack', ptr(chunk), _XDTYPE[chunk.dtype], chunk.shape[0], self.gd, chunk.stride(0), r0 // 32,
+             ptr(self.x), stream_ptr())
+
+    @property
+    def c_struct(self):
+        return ctypes.byref(self._struct)
+
+    def to_dense(self):
+        """(n, gd) float32 on the host, packed gene order (tests only)."""
+        x = self.x.cpu().numpy().reshape(self.nct, self.ngt, 2, 64, 8)          # [ct][gt][v / 8][lane][v % 8]
+        out = np.zeros((self.nct * 32, self.gd), dtype=np.float32)
+        for v in range(16):
+            for h in range(2):
+                g = 8 * (v >> 2) + 4 * h + (v & 3)
+                blk = x[:, :, v >> 3, 32 * h:32 * h + 32, v & 7]                 # [ct][gt][cell]
+                out.reshape(self.nct, 32, self.ngt, 32)[:, :, :, g] = blk.transpose(0, 2, 1)
+        return out[:self.n]
+
+
+def dense_supported(K):
+    return bool(_lib.load().oriana_dense_supported(int(K)))
 
 
 class ZWorkspace:
@@ -332,6 +457,20 @@ class ZWorkspace:
         self.stats = torch.zeros(int(_lib.load().oriana_prep_scratch_bytes()) // 4, **f32)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
+        if ct.dense is not None:
+            if not dense_supported(K):
+                raise _lib.OrianaHipError('K=%d has no dense-gene kernels (oriana_dense_supported): pack without dense_density' % K)
+            d = ct.dense
+            lib = _lib.load()
+            self.dn_S = torch.zeros(d.nct * d.ngt * 1024, **f32)
+            self.dn_flag = torch.zeros(max(d.nct * d.ngt, 1), dtype=torch.int32, device=dev)
+            pv, pu = int(lib.oriana_dense_image_pieces(K, 0)), int(lib.oriana_dense_image_pieces(K, 1))
+            self.dn_imgV = torch.empty(d.ngt * pv * 4, **f32)
+            self.dn_imgU = torch.empty(max((ct.n + 31) // 32, 1) * pu * 4, **f32)
+            nblk = max(d.nct // 8, 1)
+            self.dn_gene_splits = max(1, min(d.ngt, -(-512 // nblk)))
+            groups = (d.ngt + 7) // 8
+            self.dn_cell_splits = max(1, min((ct.n + 31) // 32, (-(-1024 // groups) + 7) // 8 * 8))
 
     def extra(self, name, rows):
         """Lazily allocated padded (rows, Kp) scratch factor / accumulator matrices."""
@@ -418,18 +557,21 @@ def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None):
          ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), stream_ptr())
 
 
-def col_pass(ct, s_cs, G, C, K):
+def col_pass(ct, s_cs, G, C, K, C_ptr=None):
+    """C += s G over the sliced layout.  `C_ptr`: device address of the first gene row of the sliced layout inside C
+    (hybrid layouts: gd rows in)."""
     w = ct.col_work_for(K)
+    Cp = ptr(C) if C_ptr is None else C_ptr
     if DETERMINISTIC and w is not None:
         nbytes = int(_lib.load().oriana_col_pass_det_scratch_bytes(int(K), int(w.shape[0])))
         key = (ct.device, nbytes)
         if key not in _det_scratch:
             _det_scratch.clear()
             _det_scratch[key] = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=ct.device)
-        call('oriana_col_pass_det', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), w.shape[0], ptr(_det_scratch[key]),
+        call('oriana_col_pass_det', ct.sparse_struct, ptr(s_cs), ptr(G), Cp, K, ptr(w), w.shape[0], ptr(_det_scratch[key]),
              stream_ptr())
         return
-    call('oriana_col_pass', ct.c_struct, ptr(s_cs), ptr(G), ptr(C), K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
+    call('oriana_col_pass', ct.sparse_struct, ptr(s_cs), ptr(G), Cp, K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 
 def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K):
@@ -455,21 +597,45 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
     partial of its single exchange ready when the column pass ends."""
     ct, K = ws.ct, ws.K
     st = stream_ptr()
+    dn = ct.dense
+    gd = ct.gd
+    # hybrid layout: the sliced layout covers the packed genes [gd, m) -- its FV / C rows start gd rows in
+    FVs, Cs = ptr(ws.FV) + 4 * gd * ws.Kp, ptr(ws.C) + 4 * gd * ws.Kp
     if phase in ('all', 'rows'):
         _check_f32(Z_hat_i, (ct.n, K)); _check_f32(Z_hat_j, (ct.m, K))
         _check_f32(log_U_hat, (ct.n, K)); _check_f32(log_V_hat, (ct.m, K))
         factor_prep_pair(ws, log_U_hat, log_V_hat)
         Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
-        with _span(ws, 'row_pass'):
-            call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), None, ptr(ws.R), ptr(ws.s_cs), None, None,
-                 ptr(ws.tile_flag), K, st)
+        if ct.ms > 0:
+            with _span(ws, 'row_pass'):
+                call('oriana_row_pass', ct.sparse_struct, ptr(ws.FU), FVs, None, ptr(ws.R), ptr(ws.s_cs), None, None,
+                     ptr(ws.tile_flag), K, st)
+        else:
+            ws.R.zero_()
+        if dn is not None:
+            with _span(ws, 'dense_images'):
+                call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
+            with _span(ws, 'dense_row'):
+                call('oriana_dense_row_pass', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S),
+                     ptr(ws.dn_flag), K, ws.dn_gene_splits, st)
         with _span(ws, 'fixup'):
-            call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat), ptr(log_V_hat),
-                 None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
+            if ct.ms > 0:
+                call('oriana_fixup', ct.sparse_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat),
+                     ptr(log_V_hat), None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
+            if dn is not None:
+                call('oriana_dense_fixup', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
+                     ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_hat_i), ptr(Z_hat_j), K, st)
         call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), ct.n, K, 1, st)
     if phase in ('all', 'cols'):
-        with _span(ws, 'col_pass'):
-            col_pass(ct, ws.s_cs, ws.FU, ws.C, K)
+        if ct.ms > 0:
+            with _span(ws, 'col_pass'):
+                col_pass(ct, ws.s_cs, ws.FU, ws.C, K, C_ptr=Cs)
+        if dn is not None:
+            with _span(ws, 'dense_images'):
+                call('oriana_dense_images', ptr(ws.dn_imgU), ptr(ws.FU), ct.n, K, 1, st)
+            with _span(ws, 'dense_col'):
+                call('oriana_dense_col_pass', dn.c_struct, ptr(ws.dn_imgU), ptr(ws.dn_S), ptr(ws.C), K,
+                     ws.dn_cell_splits, st)
         call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
 
 

@@ -59,6 +59,9 @@ def parse():
                     help='rows of the CPU baseline sample (0: sized for ~15 s of single-thread work)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--chunk-rows', type=int, default=8192)
+    ap.add_argument('--dense-density', default=os.environ.get('ORIANA_DENSE_DENSITY', 'auto'),
+                    help="pCMF: genes expressed in at least this share of the cells are evaluated on the bf16 matrix cores "
+                         "(hybrid layout); 'auto' = the engine's default, 0 = sliced layout only")
     return ap.parse_args()
 
 
@@ -128,8 +131,12 @@ def main():
     seed = 1234 + 1000 * 4
     t_setup = time.time()
     gen = SyntheticCounts(n_total, m, K, seed=seed, device=dev, zero_inflation_level=z, row0=r0, n=n)
+    dd = None
+    if mname == 'GaP' and engine.dense_supported(K):
+        dd = engine.DENSE_DENSITY_DEFAULT if args.dense_density == 'auto' else (float(args.dense_density) or None)
     counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
-                                           reduce_fn=(lambda t: odist.all_reduce_sum(t)) if world > 1 else None)
+                                           reduce_fn=(lambda t: odist.all_reduce_sum(t)) if world > 1 else None,
+                                           dense_density=dd, n_total=n_total)
     a1, b1 = gen.initial_shapes()
     model = getattr(models, mname)(counts, k=K, use_factors=False, init=(a1, b1), device=dev,
                                    process_group=(dist.group.WORLD if world > 1 else None), n_total=n_total)
@@ -166,18 +173,20 @@ def main():
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     ks = {k: v[1] * v[0] / args.steps for k, v in timer.summary().items()}       # ms per sweep and kernel group
-    pass_names = ['row_pass', 'fixup', 'row_spmm', 'col_pass', 'col_pass_log', 'DV', 'DtU', 'D_update']
+    pass_names = ['row_pass', 'dense_images', 'dense_row', 'fixup', 'row_spmm', 'col_pass', 'dense_col', 'col_pass_log', 'DV', 'DtU',
+                  'D_update']
     pass_ms = sum(ks.get(k, 0.0) for k in pass_names)
     nnz_total = odist.sum_int(counts.nnz, None if world == 1 else dist.group.WORLD, dev)
     alg_bytes = algorithmic_bytes(mname, n, m, K)
     Kp = engine.kpad(K)
     # bytes the responsibility kernels are designed to move (tiled non-zero layout): 8 B record + 4 B s (write) in
     # the row kernel, 4 B s + 1 B row index in the column kernel, + tile pointers and factor matrices
-    design_bytes = counts.nnz * 17.0 + counts.nrb * counts.ncb * (2 * 257 * 4.0 + 16) + 4.0 * Kp * (3 * n + 3 * m)
+    design_bytes = counts.nnz_sparse * 17.0 + counts.nrb * counts.ncb * (2 * 257 * 4.0 + 16) + 4.0 * Kp * (3 * n + 3 * m)
+    design_bytes += 10.0 * n * counts.gd          # dense genes: 2 B count + 4 B s written, 4 B s read per entry
     achieved = alg_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
     resp_ms = sum(ks.get(k, 0.0) for k in ('row_pass', 'fixup', 'col_pass'))
-    useful_tflops = 6.0 * counts.nnz * K / (resp_ms * 1e-3) / 1e12 if resp_ms > 0 else 0.0
-    useful_lds_gbs = 8.0 * counts.nnz * K / (resp_ms * 1e-3) / 1e9 if resp_ms > 0 else 0.0
+    useful_tflops = 6.0 * counts.nnz_sparse * K / (resp_ms * 1e-3) / 1e12 if resp_ms > 0 else 0.0
+    useful_lds_gbs = 8.0 * counts.nnz_sparse * K / (resp_ms * 1e-3) / 1e9 if resp_ms > 0 else 0.0
     check = float(model.alpha1.tensor.sum().item() + model.beta1.tensor.sum().item())
 
     # multi-GPU: per-rank pass times and the time of the sweep's packed all-reduce (measured outside the timed region)
@@ -216,7 +225,11 @@ def main():
                        'n_cells': n_total, 'n_genes': m, 'K': K, 'nnz': nnz_total, 'rows_per_rank': n,
                        'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1),
                        'hbm_gb_rank0': round(torch.cuda.max_memory_allocated() / 1e9, 1),
-                       'collectives_per_sweep': (1 + (1 if model.zi else 0)) if world > 1 else 0},
+                       'collectives_per_sweep': (1 + (1 if model.zi else 0)) if world > 1 else 0,
+                       'layout': ('hybrid: %d genes (expressed in >= %.0f%% of the cells, %.1f%% of the non-zeros) as a dense block on the '
+                                  'bf16 matrix cores (float32-equivalent: exact three-way splits, six cross products), %d genes sliced'
+                                  % (counts.gd, 100.0 * counts.dense_density, 100.0 * counts.dense.nnz / max(counts.nnz, 1), counts.ms))
+                                 if counts.gd else 'sliced non-zero layout'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'the pass of one sweep on rank 0: ' + ' + '.join(k for k in pass_names if k in ks),
@@ -358,7 +371,8 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
         Zi_o = np.empty((srows, K), np.float32)
         Zj_o = np.empty((m, K), np.float32)
         co.zq_gap(Zi_o, Zj_o, lus, lvs, Xs)
-        ct = engine.CountTiles.from_dense(torch.from_numpy(Xs).to(dev), dev)
+        # (the slab goes through the layout of the run: with a hybrid layout its densest genes take the matrix-core path)
+        ct = engine.CountTiles.from_dense(torch.from_numpy(Xs).to(dev), dev, dense_density=getattr(model.counts, 'dense_density', None))
         ws = engine.ZWorkspace(ct, K)
         Zi_h = torch.empty(srows, K, device=dev)
         Zj_h = torch.empty(m, K, device=dev)
@@ -372,7 +386,8 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
                                        'current E[log U], E[log V]: HIP vs oracle, max |d| / (|ref| + colmax|ref|)',
                 'Z_i': colrel(Zi_h.cpu().numpy(), Zi_o.astype(np.float64)),
                 'Z_j': colrel(Zj_h.cpu().numpy(), Zj_o.astype(np.float64)),
-                'conservation': float(abs(float(Zi_h.double().sum().item()) - float(Xs.astype(np.float64).sum())) / max(float(Xs.sum()), 1.0))}
+                'conservation': float(abs(float(Zi_h.double().sum().item()) - float(Xs.astype(np.float64).sum())) / max(float(Xs.sum()), 1.0)),
+                'dense_genes': int(ct.gd)}
     except Exception as e:
         slab = {'error': repr(e)}
     return cpu, slab

@@ -234,6 +234,14 @@ int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, con
                        const int32_t *row_perm, const int32_t *col_perm, float *Z_hat_i, float *Z_hat_j, int64_t K,
                        void *stream);
 
+/* Count statistics / deviance sums of the dense genes (the share of oriana_count_stats and oriana_metric_nnz that the
+ * sliced layout of a hybrid matrix does not cover): colsum, colnnz (caller's gene order), out2 += {sum (x log x - x),
+ * sum x^2}; with U, V (dense float64 (n, K), (m, K)): out4 += {sum Lambda, sum x log Lambda, sum Lambda^2,
+ * sum x Lambda} over the non-zero counts, Lambda = U V^T in float64.  Any output may be NULL. */
+int oriana_dense_metric(const oriana_dense *d, const double *U, const double *V, const int32_t *row_perm,
+                        const int32_t *col_perm, double *colsum, double *colnnz, double *out2, double *out4,
+                        int64_t K, void *stream);
+
 /* Z[o,k] = (accumulate ? Z[o,k] : 0) + F[i,k] * R[i,k] (* mul[o,k] if mul), o = row_index ? row_index[i] : i
  * -- dense (r, K) out from padded (r, Kp) in. */
 int oriana_finalize(float *Z, const float *F, const float *R, const float *mul, const int32_t *row_index,

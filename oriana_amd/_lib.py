@@ -54,6 +54,7 @@ _SIGS = {
     'oriana_dense_row_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_dense_col_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _I, _I, _P]),
     'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_dense_metric': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),
     'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _I, c_int, _P]),

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
     __syncthreads();
     f16v dn = phase_D(img);              // den of tile gt0
     int buf = 0;                         // ring position of tile gt
+    uint32_t fl = 0;                     // slow-path flags of the wave's tiles (see item 17)
     constexpr int NA = KC * 6 + (TAIL ? 2 : 0);                            // matrix instructions of D
     constexpr int NB = NT * 12;                                            // ... of R
 #ifdef ORIANA_DN_STAMP
@@ -348,7 +349,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
 #ifndef ORIANA_DN_ABL_NOSTORE
 #pragma unroll
                     for (int q = 0; q < 4; ++q) reinterpret_cast<f4v *>(sblk)[q * 64 + lane] = tq[q];
-                    flag[ct * ngt + gt] = __any(!allok) ? 1 : 0;   // one flag per (cell tile, gene tile), every lane: no branch
+                    // one flag per (cell tile, gene tile): lane (t mod 64) keeps bit t / 64 of its tile t = gt - gt0 and
+                    // the flags leave after the loop (no store, no branch here)
+                    fl |= (__any(!allok) && lane == ((gt - gt0) & 63)) ? (1u << ((gt - gt0) >> 6)) : 0u;
 #else
                     if (tq[0].x == 12345.f && __any(!allok)) reinterpret_cast<f4v *>(sblk)[lane] = tq[1] + tq[2] + tq[3];
 #endif
@@ -440,6 +443,11 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         printf("stamp blk %d w %d tiles %d: top->s15 %llu  s16-17 %llu  rest of A %llu  B %llu  vmcnt %llu  barrier %llu  (head %llu)\n", (int)blockIdx.x, w, gt1 - gt0,
                stamp_acc[1] / (gt1 - gt0), stamp_acc[2] / (gt1 - gt0), stamp_acc[3] / (gt1 - gt0), stamp_acc[4] / (gt1 - gt0), stamp_acc[5] / (gt1 - gt0), stamp_acc[6] / (gt1 - gt0), stamp_acc[0]);
 #endif
+    // ---- the flags of the strip's tiles (every entry of flag[ct][gt0 .. gt1) is written)
+    for (int j = 0; gt0 + 64 * j < gt1; ++j) {
+        const int gt = gt0 + 64 * j + lane;
+        if (gt < gt1) flag[ct * ngt + gt] = (int32_t)((fl >> j) & 1u);
+    }
     // ---- out: R[cell, k] += the strip's sums
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -645,6 +653,73 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
     }
 }
 
+// ---- metrics over the dense block (oriana_count_stats + oriana_metric_nnz for the dense genes) -------------------------
+// One work-group per (cell tile, gene tile); Lambda = U V^T in float64 at the non-zero counts.
+//   colsum[gene] += sum_i x, colnnz[gene] += #{x != 0} (caller's gene order), out2 += {sum (x log x - x), sum x^2},
+//   out4 += {sum Lambda, sum x log Lambda, sum Lambda^2, sum x Lambda}   (U, V == NULL: the constants only)
+__global__ __launch_bounds__(256) void k_dn_metric(const uint16_t *__restrict__ Xd, const double *__restrict__ U,
+                                                   const double *__restrict__ V, const int32_t *__restrict__ row_perm,
+                                                   const int32_t *__restrict__ col_perm, double *__restrict__ colsum,
+                                                   double *__restrict__ colnnz, double *__restrict__ out2,
+                                                   double *__restrict__ out4, int64_t n, int ngt, int K) {
+    extern __shared__ double fac[];                // [32 cells][K] then [32 genes][K]
+    __shared__ double red[6][4];
+    __shared__ float cs[32];
+    __shared__ int cn[32];
+    const int gt = blockIdx.x;
+    const int64_t ct = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < 32) { cs[tid] = 0.f; cn[tid] = 0; }
+    if (U) {
+        for (int e = tid; e < 32 * K; e += 256) {
+            const int r = e / K, k = e - r * K;
+            const int64_t ip = ct * 32 + r, jp = (int64_t)gt * 32 + r;
+            const int64_t i = (ip < n) ? (row_perm ? (int64_t)row_perm[ip] : ip) : -1;
+            const int64_t j = col_perm ? (int64_t)col_perm[jp] : jp;
+            fac[e] = (i >= 0) ? U[i * K + k] : 0.0;
+            fac[32 * K + e] = V[j * K + k];
+        }
+    }
+    __syncthreads();
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const uint16_t *blk = Xd + (ct * ngt + gt) * 1024;
+    for (int e = tid; e < 1024; e += 256) {
+        // entry e of the block: ((v / 8) * 64 + l) * 8 + v % 8, lane l = (cell c, half h), gene acc_row(v, h)
+        const int v = ((e >> 9) << 3) | (e & 7), l = (e >> 3) & 63;
+        const int c = l & 31, h = l >> 5, g = acc_row(v, h);
+        const uint32_t xi = blk[e];
+        if (xi == 0u) continue;
+        const double x = (double)xi;
+        a[0] += x * log(x) - x;
+        a[1] += x * x;
+        atomicAdd(&cs[g], (float)xi);               // <= 32 counts below 2^16 per gene: exact in float32
+        atomicAdd(&cn[g], 1);
+        if (U) {
+            double lam = 0.0;
+            const double *u = fac + c * K, *vv = fac + 32 * K + g * K;
+            for (int k = 0; k < K; ++k) lam += u[k] * vv[k];
+            a[2] += lam; a[3] += x * log(lam); a[4] += lam * lam; a[5] += x * lam;
+        }
+    }
+    for (int q = 0; q < 6; ++q) {
+        double t = a[q];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if ((tid & 63) == 0) red[q][tid >> 6] = t;
+    }
+    __syncthreads();
+    if (tid < 6) {
+        const double t = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        if (tid < 2) { if (out2 && t != 0.0) atomicAdd(&out2[tid], t); }
+        else if (out4 && t != 0.0) atomicAdd(&out4[tid - 2], t);
+    }
+    if (tid < 32 && cn[tid] != 0 && colsum) {
+        const int64_t jp = (int64_t)gt * 32 + tid;
+        const int64_t j = col_perm ? (int64_t)col_perm[jp] : jp;
+        atomicAdd(&colsum[j], (double)cs[tid]);
+        atomicAdd(&colnnz[j], (double)cn[tid]);
+    }
+}
+
 template <int KC, int TAIL> constexpr int row_lds_bytes() { return 3 * Cfg<KC, TAIL>::PV * 16 + NW * 32 * TS * 4; }
 template <int KC, int TAIL> constexpr int col_lds_bytes() { return 2 * Cfg<KC, TAIL>::PU * 16; }
 
@@ -755,6 +830,7 @@ extern "C" int oriana_dense_row_pass(const oriana_dense *d, const float *FU, con
     if (!FU || !imgV || !R || !S || !flag) return ORIANA_EINVAL;
     const int ngt = (int)(d->gd / 32);
     int64_t splits = gene_splits < ngt ? gene_splits : ngt;
+    if ((ngt + splits - 1) / splits > 2048) splits = (ngt + 2047) / 2048;      // (the kernel keeps one flag bit per tile in 64 x 32 bits)
     const int per = (int)((ngt + splits - 1) / splits);
     splits = (ngt + per - 1) / per;
     const dim3 grid((unsigned)(d->nct / NW), (unsigned)splits);
@@ -811,6 +887,24 @@ extern "C" int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, fl
     const int ngt = (int)(d->gd / 32);
     hipLaunchKernelGGL(k_dn_fixup, dim3((unsigned)d->nct), dim3(256), 0, (hipStream_t)stream, d->x, S,
                        flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_dense_metric(const oriana_dense *d, const double *U, const double *V, const int32_t *row_perm,
+                                   const int32_t *col_perm, double *colsum, double *colnnz, double *out2, double *out4,
+                                   int64_t K, void *stream) {
+    if (!dense_ok(d) || K <= 0 || K > 1024) return ORIANA_EINVAL;
+    if (d->gd == 0 || d->n == 0) return 0;
+    if ((U == nullptr) != (V == nullptr) || (U && !out4) || (colsum && !colnnz)) return ORIANA_EINVAL;
+    const int ngt = (int)(d->gd / 32);
+    const size_t lb = U ? (size_t)64 * K * sizeof(double) : 0;
+    if (lb > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_dn_metric, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        if (e != hipSuccess) return -1000 - (int)e;
+    }
+    hipLaunchKernelGGL(k_dn_metric, dim3((unsigned)ngt, (unsigned)((d->n + 31) / 32)), dim3(256), lb, (hipStream_t)stream, d->x, U,
+                       V, row_perm, col_perm, colsum, colnnz, out2, out4, d->n, ngt, (int)K);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -46,6 +46,7 @@ class CountTiles:
         assert self.gd % 32 == 0 and 0 <= self.gd <= self.m
         self.ms = self.m - self.gd
         self.dense = DenseBlock(self.n, self.gd, self.device) if self.gd else None
+        self.dense_density = None      # the threshold the layout was built with (from_dense / from_chunks)
         self.nrb = (self.n + TILE - 1) // TILE
         self.ncb = (self.ms + TILE - 1) // TILE
         nt = max(self.nrb * self.ncb, 1)
@@ -268,6 +269,7 @@ class CountTiles:
             cn, order, gd = cls._gene_stats(lambda: (_as_device_chunk(X, r0, min(n, r0 + rows), dev) for r0 in range(0, n, rows)),
                                             m, dev, reduce_fn, dense_density if side is None else None, n_total)
         self = cls(n, m, device, gd=gd)
+        self.dense_density = dense_density if gd else None
         self.sort_rows = bool(sort_rows)
         if order is not None:
             self.col_perm = order.to(torch.int32).contiguous()
@@ -295,6 +297,7 @@ class CountTiles:
             cn, order, gd = cls._gene_stats(lambda: (chunk_fn(r0, min(n, r0 + chunk_rows)) for r0 in range(0, n, chunk_rows)),
                                             m, torch.device(device), reduce_fn, dense_density, n_total)
         self = cls(n, m, device, gd=gd)
+        self.dense_density = dense_density if gd else None
         self.sort_rows = bool(sort_rows)
         if order is not None:
             self.col_perm = order.to(torch.int32).contiguous()
@@ -435,6 +438,20 @@ class DenseBlock:
 
 def dense_supported(K):
     return bool(_lib.load().oriana_dense_supported(int(K)))
+
+
+# Default density threshold of the hybrid layout (FactorModel(dense_density='auto')): measured break-even of the
+# matrix-core evaluation against the sliced layout on the benchmark's density profile.
+DENSE_DENSITY_DEFAULT = 0.2
+
+
+def dense_density_default():
+    e = os.environ.get('ORIANA_DENSE_DENSITY')
+    if e is None or e == '':
+        return DENSE_DENSITY_DEFAULT
+    if e.lower() in ('0', 'off', 'none', 'no'):
+        return None
+    return float(e)
 
 
 class ZWorkspace:

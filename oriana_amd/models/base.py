@@ -62,13 +62,18 @@ class FactorModel:
         already resident, sparse or row-sharded (``seed`` keys them by global row).
     device : torch device (default cuda).  process_group : torch.distributed group for row sharding.
     reference_quirks : reproduce zigap.py:94 (``D_hat[i, k]``) -- see SURVEY.md 8(a) policy.
+    dense_density : pCMF only -- genes expressed in at least this share of the cells are evaluated densely on the bf16
+        matrix cores in float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip).
+        ``'auto'``: engine.DENSE_DENSITY_DEFAULT (or the environment's ORIANA_DENSE_DENSITY; ``0`` / ``off`` disables)
+        for matrices of at least 4096 cells and a K the dense kernels are compiled for; ignored for a prebuilt
+        ``engine.CountTiles`` (its own layout is used).
     """
 
     zi = False
     sparse = False
 
     def __init__(self, cmatrix, k=2, use_factors=True, tau=0.5, init=None, device=None, process_group=None,
-                 reference_quirks=True, n_total=None, seed=0):
+                 reference_quirks=True, n_total=None, seed=0, dense_density='auto'):
         if not torch.cuda.is_available():
             raise OrianaHipError('oriana_amd needs a ROCm GPU: the CAVI kernels are HIP only (no CPU fallback)')
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
@@ -86,8 +91,11 @@ class FactorModel:
         # gene-side matrices of the on-device NMF start live in packed order): the per-gene counts that
         # define the order are summed over the shards.
         rf = (lambda t: odist.all_reduce_sum(t, process_group)) if self.world > 1 else None
+        dd = self._dense_density(dense_density, cmatrix, n_total, init)
         if isinstance(cmatrix, engine.CountTiles):
             self.counts = cmatrix
+            if cmatrix.gd and (self.zi or self.sparse):
+                raise ValueError('a hybrid (dense-gene) count layout serves pCMF (GaP) only')
         elif _is_sparse_input(cmatrix):
             A = cmatrix._sparse if hasattr(cmatrix, '_sparse') else cmatrix
             X_host = A                     # the host-side initialisation reads it in sparse form
@@ -97,7 +105,7 @@ class FactorModel:
             if not isinstance(X, torch.Tensor):
                 X = np.asarray(X)
                 X_host = X
-            self.counts = engine.CountTiles.from_dense(X, self.device, reduce_fn=rf)
+            self.counts = engine.CountTiles.from_dense(X, self.device, reduce_fn=rf, dense_density=dd, n_total=n_total)
         self.n = self.counts.n
         self.m = self.p = self.counts.m
         self.n_total = int(n_total) if n_total is not None else odist.sum_int(self.n, process_group, self.device)
@@ -147,6 +155,21 @@ class FactorModel:
         self.n_sweeps = 0
         self._graph = None
         self.initialize_parameters()
+
+    def _dense_density(self, dense_density, cmatrix, n_total, init=None):
+        """The density threshold of the hybrid layout for this model, or None."""
+        if self.zi or self.sparse or isinstance(cmatrix, engine.CountTiles) or _is_sparse_input(cmatrix):
+            return None
+        if isinstance(init, str) and init == 'nmf':      # the on-device NMF start walks the sliced layout only
+            return None
+        dd = engine.dense_density_default() if isinstance(dense_density, str) and dense_density == 'auto' else dense_density
+        if not dd or not engine.dense_supported(self.k):
+            return None
+        shape = getattr(cmatrix, 'shape', None)
+        rows = int(n_total) if n_total is not None else (int(shape[0]) if shape is not None else 0)
+        if isinstance(dense_density, str) and rows < 4096:
+            return None
+        return float(dd)
 
     # ---- initial shapes -------------------------------------------------------------------------
     def _initial_shapes(self, X_host, init):
@@ -330,7 +353,11 @@ class FactorModel:
             colsum = torch.zeros(self.m, dtype=torch.float64, device=dev)
             colnnz = torch.zeros(self.m, dtype=torch.float64, device=dev)
             out2 = torch.zeros(2, dtype=torch.float64, device=dev)
-            call('oriana_count_stats', self.counts.c_struct, ptr(colsum), ptr(colnnz), ptr(out2), stream_ptr())
+            ct = self.counts
+            call('oriana_count_stats', ct.sparse_struct, ptr(colsum), ptr(colnnz), ptr(out2), stream_ptr())
+            if ct.dense is not None:
+                call('oriana_dense_metric', ct.dense.c_struct, None, None, ptr(ct.row_perm), ptr(ct.col_perm), ptr(colsum),
+                     ptr(colnnz), ptr(out2), None, self.k, stream_ptr())
             for t in (colsum, colnnz, out2):
                 odist.all_reduce_sum(t, self.pg)
             self._xconst = (colsum, colnnz, out2)
@@ -348,10 +375,14 @@ class FactorModel:
             ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=dev)
         ws.tile_flag.zero_()
         # with these factors the row pass leaves s = x / Lambda in the row-side slots
-        call('oriana_row_pass', ct.c_struct, ptr(FU), ptr(FV), None, ptr(ws.R), ptr(ws.s_cs), None, ptr(ws.s_rs),
-             ptr(ws.tile_flag), K, st)
+        # (hybrid layout: the sliced part covers the packed genes [gd, m); the dense genes are summed in float64)
+        call('oriana_row_pass', ct.sparse_struct, ptr(FU), ptr(FV) + 4 * ct.gd * ws.Kp, None, ptr(ws.R), ptr(ws.s_cs), None,
+             ptr(ws.s_rs), ptr(ws.tile_flag), K, st)
         nz = torch.zeros(4, dtype=torch.float64, device=dev)      # sum Lambda, sum x log Lambda, sum Lambda^2, sum x Lambda
-        call('oriana_metric_nnz', ct.c_struct, ptr(ws.s_rs), ptr(U), ptr(V), K, ptr(nz), st)
+        call('oriana_metric_nnz', ct.sparse_struct, ptr(ws.s_rs), ptr(U), ptr(V), K, ptr(nz), st)
+        if ct.dense is not None:
+            call('oriana_dense_metric', ct.dense.c_struct, ptr(U), ptr(V), ptr(ct.row_perm), ptr(ct.col_perm), None, None, None,
+                 ptr(nz), K, st)
         zz = torch.zeros(2, dtype=torch.float64, device=dev)      # over Z - M: sum log(pi e^-Lambda + 1 - pi), sum Lambda^2
         if self.zi:
             call('oriana_dropout_metric', ptr(zz), ptr(self._D_hat), ptr(U), ptr(V), ptr(self.pi_d.tensor),

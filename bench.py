@@ -78,10 +78,33 @@ def self_launch(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll: the first rank to fail takes its siblings down (they would otherwise block in their next collective until
+    # the driver's limit); overall limit ORIANA_BENCH_TIMEOUT_S (default 3000 s).  Fresh children only are ever started
+    # or killed -- this process has not touched the GPU.
+    deadline = time.time() + float(os.environ.get('ORIANA_BENCH_TIMEOUT_S', '3000'))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+        if live and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+            for p in live:
+                p.terminate()
+            t_kill = time.time() + 10
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if live:
+            time.sleep(0.2)
     sys.exit(rc)
 
 
@@ -204,13 +227,31 @@ def main():
         barrier()
         allreduce_ms = (time.perf_counter() - ta) / 10 * 1e3
 
+    # ZI workloads: the same sweeps with the three dense contractions on the float64 kernels (the arithmetic the reference's
+    # np.dot uses, zigap.py:116, 124, 132) -- outside the timed region, reported beside the default (float32-equivalent) figure
+    f64_ms = None
+    if model.zi and getattr(model, '_fast_dense', False):
+        model._fast_dense = False
+        model._DV_next = None
+        for _ in range(2):
+            model.step()
+        barrier()
+        tf = time.perf_counter()
+        nf = max(3, min(args.steps, 10))
+        for _ in range(nf):
+            model.step()
+        barrier()
+        f64_ms = (time.perf_counter() - tf) / nf * 1e3
+        model._fast_dense = True
+        model._DV_next = None
+
     cpu = None
     slab = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu, slab = cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, args.cpu_rows, dev)
 
     if rank == 0:
-        traffic = recorded_traffic(args.workload, world)
+        traffic, traffic_src = recorded_traffic(args.workload, world, counts.gd > 0)
         out = {
             'metric': 'CAVI sweeps/sec (%s, %s x %s, K=%d)' % (MODEL_LABEL[mname], fmt_dim(n_total), fmt_dim(m), K),
             'value': value, 'unit': 'sweeps/s',
@@ -225,13 +266,13 @@ def main():
                        'n_cells': n_total, 'n_genes': m, 'K': K, 'nnz': nnz_total, 'rows_per_rank': n,
                        'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1),
                        'hbm_gb_rank0': round(torch.cuda.max_memory_allocated() / 1e9, 1),
-                       'collectives_per_sweep': (1 + (1 if model.zi else 0)) if world > 1 else 0,
+                       'collectives_per_sweep': (2 + (1 if model.zi else 0)) if world > 1 else 0,
                        'layout': ('hybrid: %d genes (expressed in >= %.0f%% of the cells, %.1f%% of the non-zeros) as a dense block on the '
                                   'bf16 matrix cores (float32-equivalent: exact three-way splits, six cross products), %d genes sliced'
                                   % (counts.gd, 100.0 * counts.dense_density, 100.0 * counts.dense.nnz / max(counts.nnz, 1), counts.ms))
                                  if counts.gd else 'sliced non-zero layout'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'the pass of one sweep on rank 0: ' + ' + '.join(k for k in pass_names if k in ks),
                          'algorithmic_bytes': alg_bytes, 'design_bytes': design_bytes,
                          'kernel_ms': {k: ks[k] for k in pass_names if k in ks},
@@ -249,6 +290,7 @@ def main():
                          'slot_efficiency': counts.slot_efficiency()},
             'cpu_baseline': cpu,
             'parity_slab': slab,
+            'f64_reference_arithmetic_ms': f64_ms,
             'check': check,
         }
         # launch-bound sizes: the same sweep replayed from a captured hipGraph (after, and outside, the timed region; the
@@ -273,7 +315,9 @@ def main():
         if world > 1:
             out['per_rank_ms'] = {'columns': ['row_pass', 'col_pass', 'pass'], 'ranks': per_rank}
             out['allreduce_ms'] = allreduce_ms
+            out['allreduce_share_of_step'] = allreduce_ms / ms_per_step if ms_per_step > 0 else None
             out['exchange_bytes'] = int(model._xch.numel * 4)
+            out['exchange'] = 'one step per sweep: float32 all-reduce of the per-gene sums + float64 all-reduce of the (small) rate partials'
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
@@ -288,21 +332,22 @@ def fmt_dim(v):
     return str(v)
 
 
-def recorded_traffic(workload, world):
-    """HBM bytes per launch of the pass from the committed PMC run (profiles/): the counters need
-    their own rocprofv3 passes, so the bench line quotes the recorded measurement for the
-    configuration it was taken on and null elsewhere."""
+def recorded_traffic(workload, world, hybrid=False):
+    """HBM bytes per launch of the pass from the committed PMC run (profiles/): the counters need their own rocprofv3
+    passes, so the bench line quotes the recorded measurement for the configuration AND LAYOUT it was taken on (with its
+    source) and null elsewhere."""
     if world != 1:
-        return None
-    for rnd in ('r02', 'r01'):
-        path = os.path.join(ROOT, 'profiles', '%s_pmc_hbm_%s.json' % (rnd, workload))
+        return None, None
+    tag = workload + ('_hybrid' if hybrid else '')
+    for rnd in ('r03', 'r02', 'r01'):
+        path = os.path.join(ROOT, 'profiles', '%s_pmc_hbm_%s.json' % (rnd, tag))
         if os.path.exists(path):
             try:
                 with open(path) as f:
-                    return float(json.load(f)['traffic_bytes_per_pass']['total'])
+                    return float(json.load(f)['traffic_bytes_per_pass']['total']), 'recorded: profiles/' + os.path.basename(path)
             except Exception:
-                return None
-    return None
+                return None, None
+    return None, None
 
 
 def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, rows, dev):
@@ -361,35 +406,100 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
                      '%.1f s (loop nest %.1f s), extrapolated linearly; host has %d cores, 1 used (the reference kernel is '
                      'single-threaded)' % (cls.__name__, 'ALL' if rows == n_total else 'the first', rows, n_total, t_step, t_nest, cores),
            'openmp_all_cores': omp}
-    # ---- parity slab (pCMF loop nest at the workload's K and with the model's current factors) ----
+    # ---- parity slab: the WORKLOAD's own loop nest at its K, with the model's current factors (and D_hat rows / masks) ----
     slab = None
     try:
-        srows = min(rows, 2500)
+        srows = min(rows, 2500, gen.n)
         Xs = np.ascontiguousarray(X[:srows].astype(np.float32))
         lus = np.ascontiguousarray(model._log_U_hat[:srows].cpu().numpy())
         lvs = np.ascontiguousarray(model._log_V_hat.cpu().numpy())
         Zi_o = np.empty((srows, K), np.float32)
         Zj_o = np.empty((m, K), np.float32)
-        co.zq_gap(Zi_o, Zj_o, lus, lvs, Xs)
+        Zl_o = np.empty((m, K), np.float32)
         # (the slab goes through the layout of the run: with a hybrid layout its densest genes take the matrix-core path)
         ct = engine.CountTiles.from_dense(torch.from_numpy(Xs).to(dev), dev, dense_density=getattr(model.counts, 'dense_density', None))
         ws = engine.ZWorkspace(ct, K)
         Zi_h = torch.empty(srows, K, device=dev)
         Zj_h = torch.empty(m, K, device=dev)
-        engine.zq_gap(ws, Zi_h, Zj_h, torch.from_numpy(lus).to(dev), torch.from_numpy(lvs).to(dev))
+        Zl_h = None
+        lus_d, lvs_d = torch.from_numpy(lus).to(dev), torch.from_numpy(lvs).to(dev)
+        extra = {}
+        if mname == 'GaP':
+            nest = 'gap.py:67-80'
+            co.zq_gap(Zi_o, Zj_o, lus, lvs, Xs)
+            engine.zq_gap(ws, Zi_h, Zj_h, lus_d, lvs_d)
+        elif mname == 'ZIGaP':
+            nest = 'zigap.py:79-95 (D_hat rows of the model, the D_hat[i, k] index of zigap.py:94 as the model runs it)'
+            Dh = model._D_hat[:srows].contiguous()
+            Dh_host = Dh.cpu().numpy()
+            co.zq_zigap(Zi_o, Zj_o, Zl_o, lus, lvs, Dh_host, Xs, quirk=bool(model.reference_quirks))
+            dq = Dh[:, :K].contiguous() if model.reference_quirks else None
+            engine.zq(ws, Zi_h, Zj_h, None, lus_d, lvs_d, dq=dq)
+            # the slab's rate terms of the sweep against float64 NumPy (zigap.py:116, 124, 131-136): a2 - alpha2 = D_hat V_hat,
+            # the slab's contribution to D_hat^T U_hat, and the rows of p_d (row-local given V_hat, pi_d)
+            U64 = model._U_hat[:srows].contiguous()
+            V64 = model._V_hat.contiguous()
+            Uh, Vh = U64.cpu().numpy(), V64.cpu().numpy()
+            DV_ref = Dh_host.astype(np.float64) @ Vh
+            DtU_ref = Dh_host.astype(np.float64).T @ Uh
+            DtU_h = torch.zeros(m, K, dtype=torch.float64, device=dev)
+            if model._fast_dense:
+                scr = torch.zeros(int(engine._lib.load().oriana_dense_t_scratch_floats(srows, K)), dtype=torch.float32, device=dev)
+                engine.call('oriana_dense_t_times_factor_f32', engine.ptr(DtU_h), engine.ptr(Dh), engine.ptr(U64), engine.ptr(scr),
+                            model._matrix_arith, srows, m, K, engine.stream_ptr())
+            else:
+                engine.call('oriana_dense_times_factor', engine.ptr(DtU_h), engine.ptr(Dh), engine.ptr(U64), srows, m, K, 1, engine.stream_ptr())
+            DV_h = torch.zeros(srows, K, dtype=torch.float64, device=dev)
+            engine.call('oriana_dense_times_factor', engine.ptr(DV_h), engine.ptr(Dh), engine.ptr(V64), srows, m, K, 0, engine.stream_ptr())
+            pi = model.pi_d.tensor.cpu().numpy()
+            with np.errstate(all='ignore'):
+                p_ref = co.sigmoid(co.logit(pi)[None, :] - Uh @ Vh.T)
+            p_ref[:, pi <= 0] = 1e-10
+            p_ref[:, pi >= 1] = 1. - 1e-10
+            p_ref[Xs != 0] = 1. - 1e-10
+            D_new = torch.empty(srows, m, dtype=torch.float32, device=dev)
+            nzm = torch.zeros(((srows + 31) // 32) * m, dtype=torch.int32, device=dev)
+            engine.call('oriana_nzmask_f32', engine.ptr(nzm), engine.ptr(torch.from_numpy(Xs).to(dev)), srows, m, engine.stream_ptr())
+            psum = torch.zeros(m, dtype=torch.float64, device=dev)
+            if model._fast_dense:
+                lg = torch.zeros(int(engine._lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device=dev)
+                engine.call('oriana_dropout_sweep_fused', engine.ptr(D_new), engine.ptr(U64), engine.ptr(V64), engine.ptr(model.pi_d.tensor),
+                            engine.ptr(nzm), engine.ptr(psum), None, None, engine.ptr(lg), model._matrix_arith, srows, m, K,
+                            engine.stream_ptr())
+            else:
+                engine.call('oriana_dropout_update_fused', None, engine.ptr(D_new), engine.ptr(U64), engine.ptr(V64),
+                            engine.ptr(model.pi_d.tensor), engine.ptr(nzm), engine.ptr(psum), srows, m, K, engine.stream_ptr())
+            torch.cuda.synchronize()
+            extra = {'DV_rel': float(np.abs(DV_h.cpu().numpy() - DV_ref).max() / max(np.abs(DV_ref).max(), 1e-300)),
+                     'DtU_rel': float(np.abs(DtU_h.cpu().numpy() - DtU_ref).max() / max(np.abs(DtU_ref).max(), 1e-300)),
+                     'D_hat_abs': float(np.abs(D_new.cpu().numpy().astype(np.float64) - p_ref.astype(np.float32)).max()),
+                     'p_d_colsum_rel': float(np.abs(psum.cpu().numpy() - p_ref.sum(0)).max() / max(p_ref.sum(0).max(), 1e-300)),
+                     'dense_arithmetic': 'float64' if not model._fast_dense else ('bf16x3' if model._matrix_arith == 1 and K <= 64 else 'f32 matrix instruction')}
+        else:
+            nest = 'sparse_gap.py:81-97 (S_tilde, S_hat of the model)'
+            St = np.ascontiguousarray(model._S_tilde.cpu().numpy())
+            Sh = np.ascontiguousarray(model._S_hat.cpu().numpy())
+            co.zq_sparse_gap(Zi_o, Zj_o, Zl_o, lus, lvs, St, Sh, Xs)
+            Zl_h = torch.empty(m, K, device=dev)
+            engine.zq(ws, Zi_h, Zj_h, Zl_h, lus_d, lvs_d, S_tilde=model._S_tilde, S_hat=model._S_hat)
         torch.cuda.synchronize()
 
         def colrel(got, ref):
             cm = np.abs(ref).max(axis=0, keepdims=True)
             return float((np.abs(got.astype(np.float64) - ref) / (np.abs(ref) + cm + 1e-300)).max())
-        slab = {'rows': srows, 'what': 'Z_i of the first rows and their contribution to Z_j (gap.py:67-80) from the model\'s '
-                                       'current E[log U], E[log V]: HIP vs oracle, max |d| / (|ref| + colmax|ref|)',
+        slab = {'rows': srows, 'what': 'the workload\'s loop nest (%s) on the first rows, from the model\'s current E[log U], E[log V]: '
+                                       'HIP vs oracle, max |d| / (|ref| + colmax|ref|)' % nest,
                 'Z_i': colrel(Zi_h.cpu().numpy(), Zi_o.astype(np.float64)),
                 'Z_j': colrel(Zj_h.cpu().numpy(), Zj_o.astype(np.float64)),
-                'conservation': float(abs(float(Zi_h.double().sum().item()) - float(Xs.astype(np.float64).sum())) / max(float(Xs.sum()), 1.0)),
                 'dense_genes': int(ct.gd)}
+        if mname == 'GaP':
+            slab['conservation'] = float(abs(float(Zi_h.double().sum().item()) - float(Xs.astype(np.float64).sum())) / max(float(Xs.sum()), 1.0))
+        if Zl_h is not None:
+            slab['Z_log'] = colrel(Zl_h.cpu().numpy(), Zl_o.astype(np.float64))
+        slab.update(extra)
     except Exception as e:
-        slab = {'error': repr(e)}
+        import traceback
+        slab = {'error': repr(e), 'trace': traceback.format_exc()[-600:]}
     return cpu, slab
 
 

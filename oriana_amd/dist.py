@@ -67,23 +67,24 @@ def sum_int(v, pg=None, device=None):
 
 
 class SweepExchange:
-    """The ONE sum all-reduce of a sweep: a packed float32 buffer
+    """The exchange of a sweep, issued as ONE step between the column pass and the gene-side update:
 
-        Z_j (m K) | [Z_log (m K)] | [D_hat^T U_hat: hi (m K) | lo (m K)] | sum_i U_hat, sum_i log U_hat: hi (2 K) | lo (2 K)
+        float32 buffer   Z_j (m K) | [Z_log (m K)]                                  -- one sum all-reduce
+        float64 buffer   [D_hat^T U_hat (m K)] | sum_i U_hat, sum_i log U_hat (2 K)   -- one (small) sum all-reduce
 
-    The float32 segments are views the kernels write their per-shard partials into (no copy).  The float64
-    quantities travel as two float32 words, hi = float32(x) and lo = float32(x - hi): the pair holds x to
-    ~2^-48, and what the float32 all-reduce adds to it is the rounding of the `hi` sums -- the same 1e-7
-    relative level as the float32 sums of Z_j next to them (SURVEY 8e compares sharded and single-process
-    runs at 1e-6).  On a single process nothing is packed, split or reduced: `get64` hands back the very
-    tensor `put64` was given.  The ZI models need one more, small all-reduce per sweep (the column sums of
-    p_d, which depend on the post-exchange V_hat, zigap.py:131-132, 158)."""
+    The float32 segments are views the kernels write their per-shard partials into (no copy).  The float64 partials
+    (the reference forms them in float64: zigap.py:124, gap.py:106, 120-121) are reduced EXACTLY as float64 -- a
+    float32 all-reduce of (hi, lo) pairs, as round 2 did, rounds the `hi` sums to 1e-7 and the `lo` words cannot
+    recover that.  For pCMF the second collective carries 2 K doubles.  On a single process nothing is packed or
+    reduced: `get64` hands back the very tensor `put64` was given.  The ZI models need one more small all-reduce per
+    sweep (the column sums of p_d, which depend on the post-exchange V_hat, zigap.py:131-132, 158)."""
 
     def __init__(self, device, pg, f32_shapes, f64_shapes):
         self.pg = pg
         self.world = world_size(pg)
         self.device = torch.device(device)
-        self.n_reduces = 0
+        self.n_reduces = 0            # exchanges (one per sweep)
+        self.n_collectives = 0        # all-reduce calls: one per exchange and dtype present
         self._seg32, self._seg64 = {}, {}
         off = 0
         for name, shape in f32_shapes.items():
@@ -92,29 +93,30 @@ class SweepExchange:
                 cnt *= int(d)
             self._seg32[name] = (off, cnt, tuple(int(d) for d in shape))
             off += cnt
+        self.numel32 = off
+        off = 0
         for name, shape in f64_shapes.items():
             cnt = 1
             for d in shape:
                 cnt *= int(d)
             self._seg64[name] = (off, cnt, tuple(int(d) for d in shape))
-            off += 2 * cnt
-        self.numel = off
-        self.buf = torch.zeros(max(off, 1), dtype=torch.float32, device=self.device)
+            off += cnt
+        self.numel64 = off
+        self.numel = self.numel32 + 2 * self.numel64          # in float32 words (what the exchange moves)
+        self.buf = torch.zeros(max(self.numel32, 1), dtype=torch.float32, device=self.device)
+        self.buf64 = torch.zeros(max(self.numel64, 1), dtype=torch.float64, device=self.device)
         self.f32 = {name: self.buf[o:o + c].view(shape) for name, (o, c, shape) in self._seg32.items()}
         self._local64 = {}
-        self._pending = None
+        self._pending = []
 
     def put64(self, name, t):
-        """Stage a float64 tensor of the declared shape (hi / lo split; kept as it is on one process)."""
+        """Stage a float64 tensor of the declared shape (kept as it is on one process)."""
         if self.world == 1:
             self._local64[name] = t
             return
         o, c, shape = self._seg64[name]
         assert tuple(t.shape) == shape and t.dtype == torch.float64
-        flat = t.reshape(-1)
-        hi = flat.to(torch.float32)
-        self.buf[o:o + c] = hi
-        self.buf[o + c:o + 2 * c] = (flat - hi.to(torch.float64)).to(torch.float32)
+        self.buf64[o:o + c] = t.reshape(-1)
 
     def get64(self, name, out=None):
         if self.world == 1:
@@ -124,24 +126,44 @@ class SweepExchange:
                 return out
             return t
         o, c, shape = self._seg64[name]
-        v = self.buf[o:o + c].to(torch.float64) + self.buf[o + c:o + 2 * c].to(torch.float64)
-        v = v.view(shape)
+        v = self.buf64[o:o + c].view(shape)
         if out is not None:
             out.copy_(v)
             return out
-        return v
+        return v.clone()
 
     def reduce(self, async_op=False):
-        """The collective (no-op on one process).  With async_op the caller must wait()."""
+        """The exchange (no-op on one process): both buffers are handed to the backend back to back (a float64 buffer
+        already started by start64() is not sent again).  With async_op the caller must wait()."""
         if self.world == 1:
             return
         self.n_reduces += 1
-        if async_op:
-            self._pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.pg)
+        bufs = [self.buf] if self.numel32 else []
+        if self.numel64 and not self._started64:
+            bufs.append(self.buf64)
+        self._started64 = False
+        for b in bufs:
+            self.n_collectives += 1
+            if async_op:
+                self._pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg)
+        if not async_op:
+            self.wait()
+
+    _started64 = False
+
+    def start64(self):
+        """Start the float64 all-reduce NOW, asynchronously: its partials (the cell-side column sums, D_hat^T U_hat)
+        exist before the column pass, which then runs under it; reduce() later sends the float32 buffer only and
+        waits for both."""
+        if self.world == 1 or not self.numel64:
+            return
+        self.n_collectives += 1
+        self._pending.append(dist.all_reduce(self.buf64, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._started64 = True
 
     def wait(self):
-        if self._pending is not None:
-            self._pending.wait()
-            self._pending = None
+        for h in self._pending:
+            h.wait()
+        self._pending = []

@@ -320,17 +320,32 @@ class FactorModel:
     def update_variational_parameters(self):
         raise NotImplementedError
 
-    def _exchange(self, **partials64):
-        """The one collective of a sweep: the packed buffer (per-gene float32 sums written in place by the
-        column pass, the cell-side column sums and any float64 per-gene partial handed in here) is summed over
-        the row shards.  Returns the reduced float64 partials by name."""
+    def _exchange_start(self, **partials64):
+        """First half of the sweep's exchange, called BEFORE the column pass: the float64 partials that already exist
+        (the cell-side column sums, D_hat^T U_hat of the ZI models) start their all-reduce asynchronously and the
+        column pass runs under it."""
         x = self._xch
         x.put64('sumU', self._sumU)
         for name, t in partials64.items():
             x.put64(name, t)
+        x.start64()
+        self._xch_names = tuple(partials64)
+
+    def _exchange(self, **partials64):
+        """The exchange of a sweep: the float32 buffer (per-gene sums written in place by the column pass) and the
+        float64 partials (started by _exchange_start, or handed in here) are summed over the row shards.  Returns the
+        reduced float64 partials by name."""
+        x = self._xch
+        names = getattr(self, '_xch_names', None)
+        if names is None:
+            x.put64('sumU', self._sumU)
+            for name, t in partials64.items():
+                x.put64(name, t)
+            names = tuple(partials64)
+        self._xch_names = None
         x.reduce()
         x.get64('sumU', out=self._sumU)
-        return {name: x.get64(name) for name in partials64}
+        return {name: x.get64(name) for name in names}
 
     # ---- metrics (reference base.py:58-87; loglikelihood_X: sparse_zigap.py:44-51) --------------------
     # The reference defines loglikelihood_X on SparseZIGaP only (the deviances raise AttributeError on

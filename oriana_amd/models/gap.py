@@ -25,7 +25,8 @@ class GaP(FactorModel):
         engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows')
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
         self._gamma_side('u', self._Zi, rate_vec=self._sumV[0])
+        self._exchange_start()                  # sum_i U_hat | sum_i log U_hat (float64): reduced under the column pass
         engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='cols')
-        self._exchange()                        # Z_j | sum_i U_hat | sum_i log U_hat: one all-reduce (12 MB at C4)
+        self._exchange()                        # Z_j (float32, 12 MB at C4) + wait for the sums
         # V_q: b1 = beta1 + Z_j ; b2 = beta2 + sum_i U_hat (NEW U_hat)                   gap.py:105-110
         self._gamma_side('v', self._Zj, rate_vec=self._sumU[0])

@@ -232,8 +232,9 @@ class ZIGaP(_ZIMixin, FactorModel):
         # U_q: a2 = alpha2 + D_hat V_hat (OLD V_hat)                                  zigap.py:115-120
         self._gamma_side('u', self._Zi, rate_mat=self._D_times(self._V_hat))
         DtU = self._Dt_times(self._U_hat)           # local rows, NEW U_hat
+        self._exchange_start(DtU=DtU)               # D_hat^T U_hat | column sums of U_hat (float64): reduced under the column pass
         engine.zq(*zq_args, dq=dq, phase='cols')
-        DtU = self._exchange(DtU=DtU)['DtU']        # Z_j | D_hat^T U_hat | column sums of U_hat: one all-reduce
+        DtU = self._exchange()['DtU']               # Z_j (float32) + wait for the float64 partials
         # V_q: b2 = beta2 + D_hat^T U_hat (NEW U_hat)                                 zigap.py:123-128
         self._gamma_side('v', self._Zj, rate_mat=DtU)
         # D_q (NEW U_hat, NEW V_hat), and D_hat V_hat for the next sweep's U_q         zigap.py:130-136, 116
@@ -278,8 +279,9 @@ class SparseGaP(_SparseMixin, FactorModel):
         self._sumVeff.zero_()
         call('oriana_colsum_f64', ptr(self._sumVeff), ptr(self._V_hat), ptr(self._S_hat), self.m, self.k, stream_ptr())
         self._gamma_side('u', self._Zi, rate_vec=self._sumVeff)
+        self._exchange_start()                      # column sums of U_hat (float64): reduced under the column pass
         engine.zq(*zq_args, S_tilde=self._S_tilde, S_hat=self._S_hat, phase='cols')
-        self._exchange()                            # Z_j | Z_log | column sums of U_hat: one all-reduce
+        self._exchange()                            # Z_j | Z_log (float32) + wait for the sums
         # Vprime_q: b1 = beta1 + S_hat * Z_j ; b2 = beta2 + S_hat * sum_i U_hat (NEW)  sparse_gap.py:127-132
         self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_vec=self._sumU[0], rmul=self._S_hat)
         # S_q                                                                          sparse_gap.py:134-141
@@ -328,8 +330,9 @@ class SparseZIGaP(_ZIMixin, _SparseMixin, FactorModel):
         V_old = self._Veff.clone()
         self._gamma_side('u', self._Zi, rate_mat=self._D_times(V_old))                 # sparse_zigap.py:139-144
         DtU = self._Dt_times(self._U_hat)                                               # local rows, NEW U_hat, OLD D_hat
+        self._exchange_start(DtU=DtU)               # the float64 partials: reduced under the column pass
         engine.zq(*zq_args, S_tilde=self._S_tilde, S_hat=self._S_hat, phase='cols')
-        DtU = self._exchange(DtU=DtU)['DtU']        # Z_j | Z_log | D_hat^T U_hat | column sums of U_hat: one all-reduce
+        DtU = self._exchange()['DtU']               # Z_j | Z_log (float32) + wait for D_hat^T U_hat | column sums of U_hat
         self._gamma_side('v', self._Zj, zmul=self._S_hat, rate_mat=DtU, rmul=self._S_hat)   # :147-152
         self._update_S(c_mat=DtU)                                                       # :154-161
         # :163-169; the next sweep multiplies D_hat with S_hat * Vprime_hat as they stand now (:138)

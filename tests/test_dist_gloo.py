@@ -60,7 +60,7 @@ def _sharded_gap_sweep(rank, world, port, path, out):
             Zj_t = xch.f32['Zj'].clone()
         finally:
             dist.all_reduce = real
-        assert calls == [m * K + 4 * K], calls                          # ONE collective: Z_j | sums (hi) | sums (lo)
+        assert calls == [m * K, 2 * K], calls                           # one exchange: Z_j (float32) + the sums (float64, exact)
         b1 = co.clamp(s0['beta1'][None, :] + Zj_t.numpy())
         b2 = co.clamp(np.broadcast_to(s0['beta2'] + sums[0].numpy(), b1.shape).copy())
         V_hat = co.gamma_mean(b1, b2); log_V_hat = co.gamma_meanlog(b1, b2)
@@ -90,6 +90,23 @@ def test_two_rank_sweep_matches_unsharded(tmp_path):
     assert np.array_equal(got['a2'] == 1e-15, ref['a2'] == 1e-15)
 
 
+def test_eight_rank_sweep_matches_unsharded(tmp_path):
+    """The node's full width: 257 rows over 8 ranks -- 32 rows each, the remainder (33 rows) on the last rank (the
+    remainder rule of SURVEY 8e) -- one exchange per sweep, the unsharded sweep reproduced to summation order."""
+    from oriana_amd import dist as odist
+    shards = [odist.shard_rows(257, r, 8) for r in range(8)]
+    assert shards[0] == (0, 32) and shards[-1] == (224, 257)
+    assert all(a[1] == b[0] for a, b in zip(shards[:-1], shards[1:]))
+    path = golden_files('gap_odd_rand.npz')[0]
+    out = str(tmp_path / 'sharded8.npz')
+    mp.spawn(_sharded_gap_sweep, args=(8, _free_port(), path, out), nprocs=8, join=True)
+    got = np.load(out)
+    ref = state_of(load_golden(path), 's1')
+    for k in ('a1', 'a2', 'b1', 'b2', 'alpha1', 'alpha2'):
+        assert err_colrel(got[k], ref[k]) < 2e-6, k
+    assert np.array_equal(got['a2'] == 1e-15, ref['a2'] == 1e-15)
+
+
 def _exchange_worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -106,12 +123,12 @@ def _exchange_worker(rank, world, port, out):
         real = dist.all_reduce
         dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
         xch = odist.SweepExchange('cpu', dist.group.WORLD, {'Zj': (m, K), 'Zlog': (m, K)}, {'DtU': (m, K), 'sumU': (2, K)})
-        assert xch.numel == 2 * m * K + 2 * m * K + 4 * K
+        assert xch.numel32 == 2 * m * K and xch.numel64 == m * K + 2 * K and xch.numel == 2 * m * K + 2 * m * K + 4 * K
         xch.f32['Zj'].copy_(torch.from_numpy(zj)); xch.f32['Zlog'].copy_(torch.from_numpy(zlog))
         xch.put64('DtU', torch.from_numpy(dtu)); xch.put64('sumU', torch.from_numpy(sums))
         xch.reduce()
         dist.all_reduce = real
-        assert calls == [xch.numel] and xch.n_reduces == 1
+        assert calls == [xch.numel32, xch.numel64] and xch.n_reduces == 1 and xch.n_collectives == 2
         got = dict(Zj=xch.f32['Zj'].numpy().copy(), Zlog=xch.f32['Zlog'].numpy().copy(),
                    DtU=xch.get64('DtU').numpy().copy(), sumU=xch.get64('sumU').numpy().copy())
         gathered = [None] * world
@@ -123,15 +140,18 @@ def _exchange_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_packed_exchange_is_one_collective(tmp_path):
-    """Z_j | Z_log | D_hat^T U_hat | sum U_hat | sum log U_hat travel in ONE float32 all-reduce; the
-    float64 quantities ride as (hi, lo) float32 pairs and come back at float32-sum accuracy (<= 2e-7)."""
+def test_packed_exchange_is_one_step(tmp_path):
+    """Z_j | Z_log travel in ONE float32 all-reduce (float32-sum accuracy); D_hat^T U_hat | sum U_hat |
+    sum log U_hat -- float64 in the reference -- in one float64 all-reduce issued with it, EXACT to float64 rounding."""
     out = str(tmp_path / 'xch.npz')
     mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = np.load(out)
-    for k in ('Zj', 'Zlog', 'DtU', 'sumU'):
+    for k in ('Zj', 'Zlog'):
         err = np.abs(r['got_' + k] - r['ref_' + k]) / np.abs(r['ref_' + k])
         assert err.max() < 2e-7, (k, err.max())
+    for k in ('DtU', 'sumU'):
+        err = np.abs(r['got_' + k] - r['ref_' + k]) / np.abs(r['ref_' + k])
+        assert err.max() < 1e-15, (k, err.max())
 
 
 def test_exchange_single_process_is_exact():

@@ -558,6 +558,75 @@ def test_config3_zi_full_size_properties(quirks):
     torch.cuda.empty_cache()
 
 
+def test_config3_zi_slab_against_float64_oracle():
+    """BASELINE.json configs[2] at full size on the DEFAULT (bf16 x 3) path: after two sweeps, the first 2000 cells of the
+    sweep's own loop nest (zigap.py:79-95, the model's D_hat rows and index quirk) against the C oracle, and the rate terms
+    of the next sweep -- a2 - alpha2 = D_hat V_hat (zigap.py:116), the slab's rows of D_hat^T U_hat (zigap.py:124), the
+    rows of p_d / D_hat (zigap.py:131-136, row-local given V_hat, pi_d) -- against float64 NumPy."""
+    from oracle import cavi_oracle as co
+    from oriana_amd import engine
+    from oriana_amd._lib import call, ptr, stream_ptr
+    from oriana_amd.models import ZIGaP
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K, sl = 100000, 20000, 50, 2000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip('needs ~40 GB of free HBM')
+    gen = SyntheticCounts(n, m, K, seed=6234, device='cuda', zero_inflation_level=0.1)
+    ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, 'cuda')
+    a1, b1 = gen.initial_shapes()
+    model = ZIGaP(ct, k=K, init=(a1, b1), device='cuda')
+    assert model._fast_dense and model._matrix_arith == 1
+    model.step(); model.step()
+    Xs = np.ascontiguousarray(gen.chunk(0, sl).cpu().numpy().astype(np.float32))
+    lu = np.ascontiguousarray(model._log_U_hat[:sl].cpu().numpy()); lv = np.ascontiguousarray(model._log_V_hat.cpu().numpy())
+    Dh = model._D_hat[:sl].contiguous(); Dh_host = Dh.cpu().numpy()
+    # ---- the loop nest
+    rZi = np.empty((sl, K), np.float32); rZj = np.empty((m, K), np.float32); rZl = np.empty((m, K), np.float32)
+    co.zq_zigap(rZi, rZj, rZl, lu, lv, Dh_host, Xs, quirk=True)
+    cts = engine.CountTiles.from_dense(torch.from_numpy(Xs).cuda(), 'cuda')
+    ws = engine.ZWorkspace(cts, K)
+    Zi = torch.empty(sl, K, device='cuda'); Zj = torch.empty(m, K, device='cuda')
+    engine.zq(ws, Zi, Zj, None, torch.from_numpy(lu).cuda(), torch.from_numpy(lv).cuda(), dq=Dh[:, :K].contiguous())
+    assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5
+    assert err_colrel(Zj.cpu().numpy(), rZj) < 1e-5
+    # ---- the rate terms, default arithmetic, against float64
+    U64 = model._U_hat[:sl].contiguous(); V64 = model._V_hat.contiguous()
+    Uh, Vh = U64.cpu().numpy(), V64.cpu().numpy()
+    pi = model.pi_d.tensor.cpu().numpy()
+    with np.errstate(all='ignore'):
+        p_ref = co.sigmoid(co.logit(pi)[None, :] - Uh @ Vh.T)
+    p_ref[:, pi <= 0] = 1e-10
+    p_ref[:, pi >= 1] = 1. - 1e-10
+    p_ref[Xs != 0] = 1. - 1e-10
+    D_ref = p_ref.astype(np.float32)
+    from oriana_amd import _lib
+    lib = _lib.load()
+    nzm = torch.zeros(((sl + 31) // 32) * m, dtype=torch.int32, device='cuda')
+    call('oriana_nzmask_f32', ptr(nzm), ptr(torch.from_numpy(Xs).cuda()), sl, m, stream_ptr())
+    D_new = torch.empty(sl, m, dtype=torch.float32, device='cuda')
+    psum = torch.zeros(m, dtype=torch.float64, device='cuda')
+    DV = torch.zeros(sl, K, dtype=torch.float64, device='cuda')
+    lg = torch.zeros(int(lib.oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
+    call('oriana_dropout_sweep_fused', ptr(D_new), ptr(U64), ptr(V64), ptr(model.pi_d.tensor), ptr(nzm), ptr(psum), ptr(V64),
+         ptr(DV), ptr(lg), 1, sl, m, K, stream_ptr())
+    DtU = torch.zeros(m, K, dtype=torch.float64, device='cuda')
+    scr = torch.zeros(int(lib.oriana_dense_t_scratch_floats(sl, K)), dtype=torch.float32, device='cuda')
+    call('oriana_dense_t_times_factor_f32', ptr(DtU), ptr(D_new), ptr(U64), ptr(scr), 1, sl, m, K, stream_ptr())
+    torch.cuda.synchronize()
+    assert float(np.abs(D_new.cpu().numpy().astype(np.float64) - D_ref).max()) <= 3e-7          # D_hat rows / p_d
+    assert bool((D_new.cpu().numpy()[Xs != 0] == 1.0).all())
+    DV_ref = D_ref.astype(np.float64) @ Vh                                                        # a2 - alpha2
+    DtU_ref = D_ref.astype(np.float64).T @ Uh
+    # (the matrix-core sums use the kernel's own D_hat, which differs from the float64 one by <= 3e-7 absolute per entry)
+    assert float((np.abs(DV.cpu().numpy() - DV_ref) / (np.abs(DV_ref) + 1e-300)).max()) <= 1e-6
+    assert float((np.abs(DtU.cpu().numpy() - DtU_ref) / (np.abs(DtU_ref) + np.abs(DtU_ref).max(0, keepdims=True))).max()) <= 1e-6
+    # the slab's share of pi_d = mean_i p_d (zigap.py:158): the sweep sums float32(p_d), i.e. 1 - 1e-10 counts as 1
+    assert float(np.abs(psum.cpu().numpy() - p_ref.sum(0)).max()) / sl <= 1e-7
+    del model, ct
+    torch.cuda.empty_cache()
+
+
 def test_config5_sparse_full_size():
     """BASELINE.json configs[4] (sparse pCMF, 500,000 x 25,000, K = 64) at full size on one GPU: the first sweep
     conserves the counts (S_hat = 1 at the start, sparse_gap.py:79), the active-factor mask S_tilde is

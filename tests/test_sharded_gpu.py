@@ -175,6 +175,73 @@ def test_unpacked_shards_with_device_nmf(tmp_path):
     assert err_colrel(got['a1'], single.a1.asarray()) < 1e-4
 
 
+def _hybrid_worker(rank, world, port, X, K, a1, b1, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import oriana_amd.models as M
+        from oriana_amd import dist as odist
+        r0, r1 = odist.shard_rows(X.shape[0], rank, world)
+        model = M.GaP(X[r0:r1], k=K, init=(a1[r0:r1], b1), device=torch.device('cuda', 0), process_group=dist.group.WORLD,
+                      dense_density=0.25, n_total=X.shape[0])
+        cp = model.counts.col_perm.cpu().numpy()
+        gd = model.counts.gd
+        n_coll0 = model._xch.n_collectives
+        model.fit(2)
+        per_sweep = (model._xch.n_collectives - n_coll0) / 2
+        dev = np.array([model.reconstruction_deviance(), model.frobenius_norm()])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (cp, gd, model.b1.asarray(), model.a1.asarray(), (r0, r1), per_sweep))
+        if rank == 0:
+            for g in gathered[1:]:
+                assert np.array_equal(gathered[0][0], g[0]), 'ranks disagree on the gene order'
+                assert gathered[0][1] == g[1], 'ranks disagree on the dense gene set'
+                # (the replicated gene side is recomputed on every rank; its float64 column sums are added with atomics,
+                #  so the copies agree to float64 rounding, not bit for bit)
+                np.testing.assert_allclose(g[2], gathered[0][2], rtol=1e-12, err_msg='replicated b1 diverged between the ranks')
+            np.savez(out, b1=gathered[0][2], a1=np.concatenate([g[3] for g in gathered]), gd=gd,
+                     shards=np.array([g[4] for g in gathered]), per_sweep=per_sweep, dev=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
+
+
+def test_four_ranks_hybrid_layout_uneven_split(tmp_path):
+    """Four row shards of 5003 cells (1250, 1250, 1250 and the remainder 1253) with the HYBRID layout: every rank picks
+    the same dense genes and gene order from the all-reduced counts, one exchange (float32 + float64 all-reduce) per
+    sweep, and the single-process run is reproduced to summation order.  (A GPU box admits six processes on its card:
+    four ranks + this one.)"""
+    import oriana_amd.models as M
+    rng = np.random.default_rng(21)
+    n, m, K = 5003, 400, 100
+    dens = np.clip(rng.beta(1.0, 4.0, size=m), 0.01, 1.0)
+    X = ((rng.poisson(30.0, size=(n, m)) + 1) * (rng.random((n, m)) < dens)).astype(np.float32)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    out = str(tmp_path / 'hybrid.npz')
+    mp.spawn(_hybrid_worker, args=(4, _free_port(), X, K, a1, b1, out), nprocs=4, join=True)
+    got = np.load(out)
+    assert int(got['gd']) >= 32
+    assert got['shards'].tolist() == [[0, 1250], [1250, 2500], [2500, 3750], [3750, 5003]]
+    assert float(got['per_sweep']) == 2.0
+    single = M.GaP(X, k=K, init=(a1, b1), dense_density=0.25)
+    assert single.counts.gd == int(got['gd'])
+    single.fit(2)
+    assert err_colrel(got['b1'], single.b1.asarray()) < 2e-6
+    assert err_colrel(got['a1'], single.a1.asarray()) < 2e-6
+    ref = np.array([single.reconstruction_deviance(), single.frobenius_norm()])
+    np.testing.assert_allclose(got['dev'], ref, rtol=1e-6)
+    # and the sliced layout gives the same sweep
+    pure = M.GaP(X, k=K, init=(a1, b1), dense_density=0)
+    assert pure.counts.gd == 0
+    pure.fit(2)
+    assert err_colrel(single.b1.asarray(), pure.b1.asarray()) < 5e-6
+    np.testing.assert_allclose(ref, [pure.reconstruction_deviance(), pure.frobenius_norm()], rtol=1e-6)
+
+
 def test_bench_self_launch_two_ranks():
     """`python3 bench.py --gpus 2` from a bare interpreter (no torchrun): the parent starts two fresh ranks before
     touching the GPU; with ORIANA_BENCH_ONE_GPU=1 both use cuda:0 and gloo stands in for RCCL.  One JSON line, one
@@ -192,7 +259,7 @@ def test_bench_self_launch_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
-    assert d['config']['collectives_per_sweep'] == 1
+    assert d['config']['collectives_per_sweep'] == 2       # one exchange: float32 per-gene sums + float64 rate partials
     assert len(d['per_rank_ms']['ranks']) == 2 and d['allreduce_ms'] > 0
     assert d['exchange_bytes'] == (30000 * 100 + 4 * 100) * 4
     assert 'K=100' in d['metric'] and '125k' in d['metric']

@@ -128,7 +128,8 @@ int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask
 int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
                             const int32_t *row_index_u, const int32_t *row_index_v,
                             int64_t n, int64_t m, int64_t K, float *scratch, void *stream);
-int64_t oriana_prep_scratch_bytes(void);
+int64_t oriana_prep_scratch_bytes(void);   /* includes 4096 bytes for the log-sum centres at oriana_prep_center_offset() */
+int64_t oriana_prep_center_offset(void);
 
 /* ---- the responsibility pass ----------------------------------------------------------------
  * Replaces the loop nests  GaP.compute_Z_q_expectations        (oriana/models/gap.py:67-80)
@@ -426,10 +427,21 @@ int oriana_mul_f64_f32(double *out, const double *A, const float *B, int64_t len
  * nests).  zero_guard: entries with Fin == 0 stay 0 whatever mul holds. */
 int oriana_scale_factor(float *Fout, const float *Fin, const float *mul, const int32_t *row_index,
                         int64_t r, int64_t K, int zero_guard, void *stream);
-/* Zlog[o, k] += FV[j, k] * (C2[j, k] + logV[o, k] * C[j, k]), o = row_index ? row_index[j] : j
- * (sum_i r_ijk (lu_ik + lv_jk), zigap.py:95, split into its two column sums). */
+/* The log sums sum_i r_ijk (lu_ik + lv_jk) (zigap.py:95, sparse_gap.py:97) as two column sums around a per-factor
+ * centre a_k = mean of E[log U]_ik over the contributing cells (without it the two sums are each |lu| times larger than
+ * their total once the sweeps have drifted, and the sparsity posterior amplifies the lost float32 digits):
+ *   oriana_log_center            acc[0..K) = sum w logF, acc[K..2K) = sum w over the entries that carry weight (F > 1e-20,
+ *                                finite log); w = W[., k] (dense (r, K) f32 in the caller's row order: the cell's Z_hat_i) or 1;
+ *                                acc is zeroed here
+ *   oriana_scale_factor_centered Fout = Fin * (mul - a_k), 0 where Fin == 0             (acc NULL: a = 0)
+ *   oriana_finalize_zlog         Zlog[o, k] += FV[j, k] * (C2[j, k] + (logV[o, k] + a_k) * C[j, k]), o = row_index ? row_index[j] : j,
+ *                                combined in float64 */
+int oriana_log_center(double *acc, const float *F, const float *logF, const float *W, const int32_t *row_index,
+                      int64_t r, int64_t K, void *stream);
+int oriana_scale_factor_centered(float *Fout, const float *Fin, const float *mul, const double *acc,
+                                 const int32_t *row_index, int64_t r, int64_t K, void *stream);
 int oriana_finalize_zlog(float *Zlog, const float *FV, const float *C2, const float *C, const float *logV,
-                         const int32_t *row_index, int64_t r, int64_t K, void *stream);
+                         const double *acc, const int32_t *row_index, int64_t r, int64_t K, void *stream);
 
 /* Element-wise special functions on f64 vectors (oriana/utils.py:9-15, 31-51) -- used by tests
  * and by the host mirror of oriana.utils. */

@@ -143,6 +143,34 @@ def zq_sparse_zigap(DSZ_hat, DZ_hat, DZ_exp_logsum_hat, log_U_hat, log_V_hat, S_
 # ----------------------------------------------------------------------------------------
 # utils.py
 # ----------------------------------------------------------------------------------------
+def zq_exact(log_U_hat, log_V_hat, X, S_tilde=None, S_hat=None, D_hat=None, quirk=False):
+    """The four loop nests evaluated in float64 from the same float32 inputs ("exact": what the statements of
+    gap.py:72-80 / zigap.py:84-95 / sparse_gap.py:86-97 / sparse_zigap.py:105-116 define before any float32 rounding).
+    Returns float64 (Z_i, Z_j, Z_log).  Dense n x m x K intermediate: golden sizes only.  Used to measure how far the
+    reference's own float32 evaluation and the HIP path each are from the exact value (tests, tools/parity_report.py)."""
+    lu = np.asarray(log_U_hat, dtype=np.float64); lv = np.asarray(log_V_hat, dtype=np.float64)
+    Xd = np.asarray(X, dtype=np.float64)
+    K = lu.shape[1]
+    with np.errstate(all='ignore'):
+        ls = lu[:, None, :] + lv[None, :, :]
+        e = np.exp(ls)
+        if S_tilde is not None:
+            e = e * np.asarray(S_tilde, dtype=np.float64)[None, :, :]
+        den = e.sum(axis=2)
+        den = np.where(den > 0, den, 1.0)
+        r = Xd[:, :, None] * e / den[:, :, None]
+        r = np.where(Xd[:, :, None] == 0, 0.0, r)                     # x = 0 contributes an exact 0 (0 * inf never arises in float32 either)
+        d = np.asarray(D_hat, dtype=np.float64) if D_hat is not None else None
+        wi = r if d is None else d[:, :, None] * r
+        Zi = (wi * np.asarray(S_hat, dtype=np.float64)[None, :, :]).sum(axis=1) if S_hat is not None else wi.sum(axis=1)
+        if d is not None and quirk:
+            Zj = (d[:, :K][:, None, :] * r).sum(axis=0)               # zigap.py:94: D_hat[i, k]
+        else:
+            Zj = wi.sum(axis=0)
+        Zlog = (wi * np.where(r == 0, 0.0, ls)).sum(axis=0)
+    return Zi, Zj, Zlog
+
+
 def logit(x):
     """utils.py:9-11"""
     x = np.clip(x, 1e-15, 1. - 1e-15)
@@ -209,6 +237,8 @@ class _OracleModel:
 
     zi = False       # has the dropout node D (zigap.py, sparse_zigap.py)
     sparse = False   # has the sparsity node S (sparse_gap.py, sparse_zigap.py)
+    exact = False    # True: the loop nest in float64 (zq_exact) instead of the reference's float32 -- the yardstick both the
+                     # reference and the HIP path are measured against (tools/parity_report.py); everything else unchanged
 
     def __init__(self, X, k, init_a1, init_b1, tau=0.5, reference_quirks=True):
         self.X = np.asarray(X)
@@ -276,7 +306,11 @@ class _OracleModel:
         Zlog = np.empty((m, K), dtype=np.float32)
         if self.sparse:
             S_tilde = (self.p_s > self.tau).astype(np.float32)       # sparse_gap.py:113
-        if not self.zi and not self.sparse:
+        if self.exact:
+            Zi, Zj, Zlog = zq_exact(self.log_U_hat, self.log_V_hat, self.Xf, S_tilde if self.sparse else None,
+                                    self.S_hat if self.sparse else None, self.D_hat if self.zi else None,
+                                    quirk=(self.zi and not self.sparse and self.reference_quirks))
+        elif not self.zi and not self.sparse:
             zq_gap(Zi, Zj, self.log_U_hat, self.log_V_hat, self.Xf)               # gap.py:89-94
         elif self.zi and not self.sparse:
             zq_zigap(Zi, Zj, Zlog, self.log_U_hat, self.log_V_hat, self.D_hat, self.Xf,

@@ -87,7 +87,10 @@ _SIGS = {
     'oriana_threshold_f32': (c_int, [_P, _P, c_double, _I, _P]),
     'oriana_rowmean_f64': (c_int, [_P, _P, _I, _I, _P]),
     'oriana_scale_factor': (c_int, [_P, _P, _P, _P, _I, _I, c_int, _P]),
-    'oriana_finalize_zlog': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_finalize_zlog': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_log_center': (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_scale_factor_centered': (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_prep_center_offset': (_I, []),
     'oriana_digamma_f64': (c_int, [_P, _P, _I, _P]),
     'oriana_trigamma_f64': (c_int, [_P, _P, _I, _P]),
     'oriana_inverse_digamma_f64': (c_int, [_P, _P, _I, _P]),

@@ -157,11 +157,70 @@ __global__ __launch_bounds__(256) void k_scale_factor(float *__restrict__ Fout, 
     Fout[idx] = v;
 }
 
-// Zlog[o,k] += FV[j,k] * (C2[j,k] + lv[o,k] * C[j,k])   (zigap.py:95 re-associated, o = row_index[j])
+// The log sums sum_i r_ijk (lu_ik + lv_jk) (zigap.py:95) are evaluated as FV (sum_i s FU (lu - a_k)) + (lv + a_k) FV sum_i s FU
+// with a per-factor centre a_k: split as two plain sums (a = 0) the two terms are each |lu| times larger than their
+// sum when the sweeps have drifted along the scale indeterminacy (lu ~ +45, lv ~ -27), and the float32 column sums then
+// lose that factor in precision -- the sparsity posterior p_s = sigmoid(logit(pi_s) - (c V' - Zlog)) amplifies it (measured:
+// 1.4e-4 on p_s against 2e-6 for the reference's own float32 loop).  a_k = mean of lu_ik over the
+// cells that carry weight (FU_ik > 1e-20 of the row's largest factor, finite log), weighted by the cell's own
+// responsibility sums Z_i[i, k] when they are at hand (the r-weighted mean of lu): acc = {sum w lu, sum w} per factor.
+__global__ __launch_bounds__(256) void k_log_center(double *__restrict__ acc, const float *__restrict__ F,
+                                                    const float *__restrict__ logF, const float *__restrict__ W,
+                                                    const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
+    __shared__ double ssum[256];
+    __shared__ double scnt[256];
+    ssum[threadIdx.x] = 0.0;
+    scnt[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row < r) {
+        const int64_t src = row_index ? (int64_t)row_index[row] : row;
+        for (int k = 0; k < K; ++k) {
+            const float f = F[row * Kp + k], l = logF[src * K + k];
+            if (f > 1e-20f && fabsf(l) < 1e30f) {          // (a rejected row is the constant 1e-30: it never counts)
+                const double w = W ? (double)W[src * K + k] : 1.0;
+                if (w > 0.0 && w < 1e300) {
+                    atomicAdd(&ssum[k], w * (double)l);
+                    atomicAdd(&scnt[k], w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < K && scnt[threadIdx.x] > 0.0) {
+        atomicAdd(&acc[threadIdx.x], ssum[threadIdx.x]);
+        atomicAdd(&acc[K + threadIdx.x], scnt[threadIdx.x]);
+    }
+}
+
+__device__ __forceinline__ double log_center(const double *__restrict__ acc, int K, int k) {
+    if (!acc) return 0.0;
+    const double c = acc[K + k];
+    return c > 0.0 ? acc[k] / c : 0.0;
+}
+
+// Fout[i, k] = Fin[i, k] * (mul[src(i), k] - a_k), 0 where Fin == 0 (the E[log U]-weighted factor of the log sums)
+__global__ __launch_bounds__(256) void k_scale_factor_centered(float *__restrict__ Fout, const float *__restrict__ Fin,
+                                                               const float *__restrict__ mul, const double *__restrict__ acc,
+                                                               const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= r * Kp) return;
+    const int64_t row = idx / Kp;
+    const int k = (int)(idx - row * Kp);
+    float v = 0.f;
+    if (k < K) {
+        const float f = Fin[idx];
+        const int64_t src = row_index ? (int64_t)row_index[row] : row;
+        if (f != 0.f) v = f * (float)((double)mul[src * K + k] - log_center(acc, K, k));
+    }
+    Fout[idx] = v;
+}
+
+// Zlog[o,k] += FV[j,k] * (C2[j,k] + (lv[o,k] + a_k) * C[j,k])   (o = row_index[j]; combined in float64)
 __global__ __launch_bounds__(256) void k_finalize_zlog(float *__restrict__ Zlog, const float *__restrict__ FV,
                                                        const float *__restrict__ C2, const float *__restrict__ C,
-                                                       const float *__restrict__ logV, const int32_t *__restrict__ row_index,
-                                                       int64_t r, int K, int Kp) {
+                                                       const float *__restrict__ logV, const double *__restrict__ acc,
+                                                       const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= r * K) return;
     const int64_t row = idx / K;
@@ -169,7 +228,8 @@ __global__ __launch_bounds__(256) void k_finalize_zlog(float *__restrict__ Zlog,
     const int64_t o = (row_index ? (int64_t)row_index[row] : row) * K + k;
     const float f = FV[row * Kp + k];
     float v = 0.f;
-    if (f != 0.f) v = f * fmaf(logV[o], C[row * Kp + k], C2[row * Kp + k]);
+    if (f != 0.f)
+        v = (float)((double)f * ((double)C2[row * Kp + k] + ((double)logV[o] + log_center(acc, K, k)) * (double)C[row * Kp + k]));
     Zlog[o] += v;
 }
 
@@ -301,15 +361,44 @@ extern "C" int oriana_scale_factor(float *Fout, const float *Fin, const float *m
     return 0;
 }
 
+extern "C" int oriana_log_center(double *acc, const float *F, const float *logF, const float *W, const int32_t *row_index,
+                                 int64_t r, int64_t K, void *stream) {
+    const int64_t Kp = oriana_kpad(K);
+    if (r < 0 || K <= 0) return ORIANA_EINVAL;
+    if (Kp == 0) return ORIANA_EKRANGE;
+    if (!acc) return ORIANA_EINVAL;
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 2 * K, (hipStream_t)stream);
+    if (e != hipSuccess) return -1000 - (int)e;
+    if (r == 0) return 0;
+    if (!F || !logF) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_log_center, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, F, logF,
+                       W, row_index, r, (int)K, (int)Kp);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_scale_factor_centered(float *Fout, const float *Fin, const float *mul, const double *acc,
+                                            const int32_t *row_index, int64_t r, int64_t K, void *stream) {
+    const int64_t Kp = oriana_kpad(K);
+    if (r < 0 || K <= 0) return ORIANA_EINVAL;
+    if (Kp == 0) return ORIANA_EKRANGE;
+    if (r == 0) return 0;
+    if (!Fout || !Fin || !mul) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_scale_factor_centered, dim3((unsigned)((r * Kp + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       Fout, Fin, mul, acc, row_index, r, (int)K, (int)Kp);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int oriana_finalize_zlog(float *Zlog, const float *FV, const float *C2, const float *C, const float *logV,
-                                    const int32_t *row_index, int64_t r, int64_t K, void *stream) {
+                                    const double *acc, const int32_t *row_index, int64_t r, int64_t K, void *stream) {
     const int64_t Kp = oriana_kpad(K);
     if (r < 0 || K <= 0) return ORIANA_EINVAL;
     if (Kp == 0) return ORIANA_EKRANGE;
     if (r == 0) return 0;
     if (!Zlog || !FV || !C2 || !C || !logV) return ORIANA_EINVAL;
     hipLaunchKernelGGL(k_finalize_zlog, dim3((unsigned)((r * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Zlog,
-                       FV, C2, C, logV, row_index, r, (int)K, (int)Kp);
+                       FV, C2, C, logV, acc, row_index, r, (int)K, (int)Kp);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -1638,7 +1638,8 @@ extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const 
     return 0;
 }
 
-extern "C" int64_t oriana_prep_scratch_bytes(void) { return (int64_t)sizeof(float) * (8 + 3 * 2 * STATS_MAX_BLOCKS); }
+extern "C" int64_t oriana_prep_center_offset(void) { return ((int64_t)sizeof(float) * (8 + 3 * 2 * STATS_MAX_BLOCKS) + 7) / 8 * 8; }
+extern "C" int64_t oriana_prep_scratch_bytes(void) { return oriana_prep_center_offset() + 4096; }
 
 extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
                                        const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,

@@ -202,9 +202,11 @@ static int zq_dense(float *Zi, float *Zj, float *Zlog, const float *log_U_hat, c
             if ((rc = oriana_col_pass(&cm, s_log, FU, C, K, nullptr, 0, stream))) return rc;
         }
         ORIANA_HIP_CHECK(hipMemsetAsync(C2, 0, sizeof(float) * m * L.Kp, s));
-        if ((rc = oriana_scale_factor(G2, FU, log_U_hat, nullptr, n, K, 1, stream))) return rc;
+        double *center = (double *)((char *)prep + oriana_prep_center_offset());
+        if ((rc = oriana_log_center(center, FU, log_U_hat, Zi, nullptr, n, K, stream))) return rc;
+        if ((rc = oriana_scale_factor_centered(G2, FU, log_U_hat, center, nullptr, n, K, stream))) return rc;
         if ((rc = oriana_col_pass(&cm, s_log, G2, C2, K, nullptr, 0, stream))) return rc;
-        if ((rc = oriana_finalize_zlog(Zlog, FV, C2, C, log_V_hat, nullptr, m, K, stream))) return rc;
+        if ((rc = oriana_finalize_zlog(Zlog, FV, C2, C, log_V_hat, center, nullptr, m, K, stream))) return rc;
     }
     return 0;
 }

@@ -472,6 +472,7 @@ class ZWorkspace:
         self.tile_flag = torch.zeros(max(ct.nrb * ct.ncb, 1), dtype=torch.int32, device=dev)
         # statistics of the row maxima of E[log U], E[log V] and the partial sums they are built from (zeroed ONCE)
         self.stats = torch.zeros(int(_lib.load().oriana_prep_scratch_bytes()) // 4, **f32)
+        self.center_ptr = ptr(self.stats) + int(_lib.load().oriana_prep_center_offset())    # {sum, count} of E[log U] per factor (log sums)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
         if ct.dense is not None:
@@ -731,7 +732,8 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         if Z_log is not None:
             # E[log U]-weighted row factor of the log sums: built NOW, from the pre-update E[log U] (the caller
             # may run the cell-side update between the two phases)
-            call('oriana_scale_factor', ptr(ws.extra('GL', n)), ptr(ws.FU), ptr(log_U_hat), ptr(ct.row_perm), n, K, 1, st)
+            call('oriana_log_center', ws.center_ptr, ptr(ws.FU), ptr(log_U_hat), ptr(Z_i), ptr(ct.row_perm), n, K, st)
+            call('oriana_scale_factor_centered', ptr(ws.extra('GL', n)), ptr(ws.FU), ptr(log_U_hat), ws.center_ptr, ptr(ct.row_perm), n, K, st)
     if phase == 'rows':
         return
     # per-gene sums: weighted by D_hat[i, j] (sw), or -- zigap.py:94 -- by D_hat[i, k] on the plain s
@@ -765,7 +767,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         if not dual_done:
             with _span(ws, 'col_pass_log'):
                 col_pass(ct, s_log, G2, C2, K)
-        call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ptr(ct.col_perm), m, K, st)
+        call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ws.center_ptr, ptr(ct.col_perm), m, K, st)
 
 
 def _stateless_ws(n, m, K, X):

@@ -20,8 +20,9 @@ RTOL = 1e-5   # BASELINE.json north_star: "within 1e-5 relative on the variation
 # multi-tile / sharded cases (|d p_d| <= 0.25 |d Lambda|, Lambda carries the 1e-6 relative error of U_hat, V_hat).
 KEY_ATOL = {'p_d': 2e-6, 'pi_d': 1e-7}
 # The sparsity posterior p_s = sigmoid(logit(pi_s) - t), t a float32 difference of two sums of magnitude 1e4..1e6,
-# is bounded by its conditioning wherever a test can compute it (sparsity_tolerance below; measured 1.4e-4 absolute
-# against the reference, inside that bound); 1e-4 is only the fallback for comparisons of untouched initial states.
+# is judged against the EXACT value of the same sweep wherever a test can compute it (exact_twin below: HIP within
+# 7.1e-6, the reference's own arithmetic within 2.0e-6); 1e-4 is only the fallback for comparisons of untouched
+# initial states.
 KEY_RTOL = {'p_s': 1e-4, 'pi_s': 1e-4, 'S_hat': 1e-4}
 
 
@@ -63,37 +64,38 @@ def err_colrel(got, ref):
     return float(np.max(d))
 
 
-def sparsity_tolerance(oracle_model):
-    """Absolute tolerance of the sparsity posterior p_s = sigmoid(logit(pi_s) - t),
-    t = -Zlog + c * Vprime (sparse_gap.py:135-137), after `oracle_model.step()`.
+def exact_twin(oracle_model):
+    """A copy of an oracle model (BEFORE its step) whose loop nest runs in float64 (cavi_oracle.zq_exact): the yardstick
+    the reference's float32 evaluation and the HIP path are both measured against for the sparsity posterior.
 
-    t is a float32 difference of two large sums (|Zlog|, |c Vprime| reach 1e4..1e6 while t is
-    O(10) where p_s is not saturated), so its absolute error is RTOL x (|Zlog| + |c Vprime|) for
-    ANY float32 evaluation order -- the reference's own included -- and p_s moves by at most a
-    quarter of that (max slope of the sigmoid).  Returns (m, K) bounds for p_s / S_hat and (m,)
-    for pi_s = mean_k p_s."""
-    M = oracle_model
-    Zlog = np.abs(M.last_Z[2].astype(np.float64))
-    if M.zi:
-        c = np.abs(np.dot(M.last_D_hat.T.astype(np.float64), M.U_hat))
-    else:
-        c = np.abs(np.broadcast_to(M.U_hat.sum(axis=0), Zlog.shape))
-    scale = Zlog + c * np.abs(M.V_hat) + 1.0
-    tol = 0.25 * RTOL * scale + 1e-6
-    return tol, tol.mean(axis=1)
+    p_s = sigmoid(logit(pi_s) - t), t = -Zlog + c * Vprime (sparse_gap.py:135-137), is a difference of two sums of
+    magnitude 1e3..1e6 that leaves t = O(10): every float32 evaluation of the loop nest -- the reference's own included --
+    moves it.  Measured on the goldens (profiles/r03_parity_errors.json): the reference is up to 2.0e-6 away from the
+    exact p_s, the HIP path up to 7.1e-6 (1.4e-4 in round 2, before the log sums were centred)."""
+    import copy
+    E = copy.deepcopy(oracle_model)
+    E.exact = True
+    return E
 
 
-def assert_state_close(got, ref, rtol=RTOL, keys=None, what='', ps_tol=None):
+PS_FLOOR = {'p_s': 2e-5, 'S_hat': 2e-5, 'pi_s': 3e-6}     # absolute, against the EXACT value (measured worst: 7.1e-6 / 1.0e-6)
+PS_FACTOR = 16.0                                           # ... or this many times the reference's own distance from exact
+
+
+def assert_state_close(got, ref, rtol=RTOL, keys=None, what='', exact=None):
     """|got - ref| <= rtol*|ref| + rtol*colmax|ref| on every key, plus identical clamp
-    patterns (entries sitting exactly on the 1e-15 floor / the 1-1e-10 ceiling)."""
+    patterns (entries sitting exactly on the 1e-15 floor / the 1-1e-10 ceiling).  `exact`: the state of the exact twin
+    of the same sweep -- the sparsity posterior is then judged against IT: the HIP value may be no further from exact
+    than PS_FLOOR, or PS_FACTOR times the distance of `ref` (the reference's float32 arithmetic) from exact."""
     keys = keys or [k for k in PARAM_KEYS + EXPECT_KEYS if k in ref]
     for k in keys:
         if k not in ref or k not in got:
             continue
-        if ps_tol is not None and k in ('p_s', 'S_hat', 'pi_s'):
-            bound = ps_tol[1] if k == 'pi_s' else ps_tol[0]
-            d = np.abs(np.asarray(got[k], dtype=np.float64) - np.asarray(ref[k], dtype=np.float64))
-            assert (d <= bound).all(), '%s %s: max err/bound %.3e' % (what, k, float((d / bound).max()))
+        if exact is not None and k in PS_FLOOR:
+            d_hip = float(np.abs(np.asarray(got[k], dtype=np.float64) - np.asarray(exact[k], dtype=np.float64)).max())
+            d_ref = float(np.abs(np.asarray(ref[k], dtype=np.float64) - np.asarray(exact[k], dtype=np.float64)).max())
+            assert d_hip <= max(PS_FLOOR[k], PS_FACTOR * d_ref), \
+                '%s %s: HIP is %.3e from exact, the reference arithmetic %.3e' % (what, k, d_hip, d_ref)
             continue
         if k in KEY_ATOL:
             e = float(np.max(np.abs(np.asarray(got[k], dtype=np.float64) - np.asarray(ref[k], dtype=np.float64)))) if np.size(ref[k]) else 0.0

@@ -83,7 +83,7 @@ def test_two_ranks_match_one(tmp_path, name, fn):
     ref = single.state()
     # Sharding changes the summation order only (float atomics already make it run-dependent).  The
     # Gamma parameters move by ~1e-7 per sweep; the Bernoulli posteriors amplify that through the
-    # sigmoid (helpers.sparsity_tolerance), so they get an absolute 1e-3 here -- this test is about
+    # sigmoid (helpers.exact_twin), so they get an absolute 1e-3 here -- this test is about
     # the sharding logic, the conditioning is covered by tests/test_models_gpu.py.
     for k in got.files:
         if k == 'metrics':

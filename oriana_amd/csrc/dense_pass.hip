@@ -85,7 +85,9 @@ constexpr int NW = 8;             // waves per work-group
 //   second image (B operand of the accumulation)  [n tile][instruction q][split][lane = 32 hh + cc]:
 //                F[acc_row(8 q + e, hh)][32 nt + cc], e = 0..7 -- the rows in the order the accumulator registers of
 //                the first product hold them
-//   tail         32 rows x float4 (factors 16 KC .. 16 KC + 3), plain float32
+//   tail         32 rows x float4 (factors 16 KC .. 16 KC + 3), plain float32; then the same values as
+//                [lane half][tail factor][16 rows in accumulator order]: the B operand of the 4 x 4 x 1 float32 instructions
+//                that accumulate the tail factors (lane l = 4 b + j of block b supplies B[b][j])
 template <int KC, int TAIL>
 struct Cfg {
     static constexpr int NT = (KC + 1) / 2;
@@ -139,9 +141,18 @@ __global__ __launch_bounds__(512) void k_dn_images(u4v *__restrict__ img, const 
         }
     }
     if (TAIL && tid < 64) {
-        const int64_t r = r0 + tid;
         f4v t = {0.f, 0.f, 0.f, 0.f};
-        if (tid < 32 && r < rows) t = *reinterpret_cast<const f4v *>(F + r * Kp + C::KM);
+        if (tid < 32) {                              // pieces 0..31: the four tail factors of row tid
+            const int64_t r = r0 + tid;
+            if (r < rows) t = *reinterpret_cast<const f4v *>(F + r * Kp + C::KM);
+        } else {                                     // pieces 32..63: [lane half hh][tail factor j][4 q .. 4 q + 3]: the
+            const int idx = tid - 32, hh = idx >> 4, j = (idx >> 2) & 3, q = idx & 3;   // rows in accumulator order
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t r = r0 + acc_row(4 * q + e, hh);
+                t[e] = (r < rows) ? F[r * Kp + C::KM + j] : 0.f;
+            }
+        }
         dst0[(BOTH ? C::P1 : 0) + C::P2 + tid] = __builtin_bit_cast(u4v, t);
     }
 }
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
     const float futb0 = h ? fut.y : fut.x, futb1 = h ? fut.w : fut.z;
 
     f16v rs[NT];                         // R of the strip: [cell acc_row(v, h)][factor 32 nt + c]
-    f4v rt = {0.f, 0.f, 0.f, 0.f};       // tail factors of cell c, this half's genes
+    f4v rt = {0.f, 0.f, 0.f, 0.f};       // tail factors: 4 x 4 blocks (cells x factors), this half's genes
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         uint32_t sh = 0, sm = 0, sl = 0;                                   // bf16 parts of the even value of a pair
         float tl0 = 0.f, tl2 = 0.f;
         const f4v *tails = reinterpret_cast<const f4v *>(im0 + C::P1 + C::P2);
-        f4v ftn = {0.f, 0.f, 0.f, 0.f};
+        f4v t2[4];
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             // ---- matrix instruction
@@ -344,7 +355,10 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     image_dma<C::PV>(imgV + (int64_t)g2 * C::PV, img + bufnn * C::PV, w, lane);
 #endif
                 } else if (it == 17) {
-                    if (TAIL) ftn = tails[acc_row(0, h)];
+                    if (TAIL) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) t2[q] = tails[32 + (h * 4 + (lane & 3)) * 4 + q];
+                    }
                     float *sblk = srow + (int64_t)gt * 1024;
 #ifndef ORIANA_DN_ABL_NOSTORE
 #pragma unroll
@@ -364,11 +378,10 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u);
                     const uint32_t c0 = __float_as_uint(r0);
                     const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u);
-                    if (TAIL) {          // R's tail factors of this value (plain float32), the next value's tail in flight
-                        const f4v ft = ftn;
-                        if (vv + 1 < 16) ftn = tails[acc_row(vv + 1, h)];
-                        rt.x = fmaf(x0, ft.x, rt.x); rt.y = fmaf(x0, ft.y, rt.y);
-                        rt.z = fmaf(x0, ft.z, rt.z); rt.w = fmaf(x0, ft.w, rt.w);
+                    if (TAIL) {
+                        // R's tail factors: 16 blocks of 4 cells x 4 factors, one gene per instruction -- A[b][i] = s of cell
+                        // 4 (b % 8) + i (this lane's value), B[b][j] = FV[gene][KM + j]: exact float32 FMAs on the matrix pipe
+                        rt = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, t2[vv >> 2][vv & 3], rt, 0, 0, 0);
                     }
                     if ((vv & 1) == 0) { sh = b0; sm = c0; sl = __float_as_uint(s0); }
                     else {
@@ -462,12 +475,19 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
             }
         }
     if (TAIL) {
+        // lane 4 b + j holds, in register e, the tail sum of cell 4 (b % 8) + e and factor KM + j over its half's genes
         rt.x += __shfl_xor(rt.x, 32, 64); rt.y += __shfl_xor(rt.y, 32, 64);
         rt.z += __shfl_xor(rt.z, 32, 64); rt.w += __shfl_xor(rt.w, 32, 64);
-        if (h == 0 && i < n) {
-            float *p = R + i * Kp + C::KM;
-            if (atomic_out) { atomicAdd(p, rt.x); atomicAdd(p + 1, rt.y); atomicAdd(p + 2, rt.z); atomicAdd(p + 3, rt.w); }
-            else { f4v o = *reinterpret_cast<f4v *>(p); o += rt; *reinterpret_cast<f4v *>(p) = o; }
+        if (h == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t cell = ct * 32 + 4 * (lane >> 2) + e;
+                if (cell < n) {
+                    float *p = R + cell * Kp + C::KM + (lane & 3);
+                    if (atomic_out) atomicAdd(p, rt[e]);
+                    else *p += rt[e];
+                }
+            }
         }
     }
 }
@@ -475,6 +495,13 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
 // ---- gene side -----------------------------------------------------------------------------------------------------
 // grid.x = nsplit * ngroups, work-group (split, group) = blockIdx.x % nsplit, blockIdx.x / nsplit: the groups of one
 // split -- which stage the same cell images -- are dispatched next to each other.
+// Every global read is an LDS-DMA copy (the cell images shared by the 8 waves: ring of three; the wave's own tile of s:
+// ring of two), issued TWO tiles ahead; the vector-memory counter retires in issue order, so "at most the seven copies
+// of this iteration outstanding" means the previous iteration's have landed.  The partial sums stay on the matrix core
+// for 8 tiles (256 cells: inside the regime where the bf16 x 3 chain carries the float32 chain's error) and then join
+// the running float32 sums; the four tail factors go through v_mfma_f32_4x4x1_16B_f32 (exact float32 FMAs).
+constexpr int COL_FLUSH = 8;
+
 template <int KC, int TAIL>
 __global__ __launch_bounds__(512) void k_dn_col(const float *__restrict__ S, const u4v *__restrict__ imgU,
                                                 float *__restrict__ Cout, int64_t nct, int ngt, int Kp,
@@ -482,9 +509,10 @@ __global__ __launch_bounds__(512) void k_dn_col(const float *__restrict__ S, con
     using C = Cfg<KC, TAIL>;
     constexpr int NT = C::NT;
     extern __shared__ u4v ldsq[];
-    u4v *img = ldsq;                                                      // [2][PU]
+    u4v *img = ldsq;                                                      // [3][PU]
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u4v *sbuf = ldsq + 3 * C::PU + w * 256;                               // [2][8 waves][256 pieces]: + 2048 per ring slot
     const int split = blockIdx.x % nsplit, grp = blockIdx.x / nsplit;
     const int gt = grp * NW + w;
     const bool active = gt < ngt;
@@ -493,30 +521,40 @@ __global__ __launch_bounds__(512) void k_dn_col(const float *__restrict__ S, con
     const int64_t ct1 = (ct0 + ct_per_split < nct) ? ct0 + ct_per_split : nct;
     if (ct0 >= ct1) return;
 
-    f16v cs[NT];                         // C of the wave's genes: [gene acc_row(v, h)][factor 32 nt + c]
-    f4v cta = {0.f, 0.f, 0.f, 0.f};      // tail factors of gene c, this half's cells
+    f16v cs[NT], dv[NT];                 // C of the wave's genes: [gene acc_row(v, h)][factor 32 nt + c]; dv: on the matrix core
+    f4v cta = {0.f, 0.f, 0.f, 0.f};      // tail factors: 4 x 4 blocks (genes x factors), this half's cells
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) cs[nt][v] = 0.f;
+        for (int v = 0; v < 16; ++v) { cs[nt][v] = 0.f; dv[nt][v] = 0.f; }
 
-    f4v sn[4];
-    image_dma<C::PU>(imgU + ct0 * C::PU, img, w, lane);
+    auto issue = [&](int64_t ct, int islot, int sslot) {
+        const int64_t cc = ct < ct1 ? ct : ct1 - 1;
+        image_dma<C::PU>(imgU + cc * C::PU, img + islot * C::PU, w, lane);
+        const u4v *src = reinterpret_cast<const u4v *>(S + (cc * ngt + gtc) * 1024);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sn[q] = reinterpret_cast<const f4v *>(S + (ct0 * ngt + gtc) * 1024)[q * 64 + lane];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int buf = 0;
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(sbuf + sslot * 2048 + q * 64), 16, 0, 0);
+    };
+    constexpr int NCOPY = C::PU / (NW * 64) + 4;                          // LDS-DMA instructions per wave and tile
+    static_assert(NCOPY >= 5 && NCOPY <= 7, "the waits below count the copies of one iteration");
+    auto wait_prev = [&]() {             // the previous iteration's copies have landed, this iteration's may be in flight
+        if (NCOPY == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (NCOPY == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    };
+    issue(ct0, 0, 0);
+    issue(ct0 + 1, 1, 1);
+    wait_prev();
+    __builtin_amdgcn_s_barrier();
+    int islot = 0, sslot = 0, since = 0;
     for (int64_t ct = ct0; ct < ct1; ++ct) {
-        f4v sc[4] = {sn[0], sn[1], sn[2], sn[3]};
-        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
-        if (ct + 1 < ct1) {
-            image_dma<C::PU>(imgU + (ct + 1) * C::PU, img + (buf ^ 1) * C::PU, w, lane);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sn[q] = reinterpret_cast<const f4v *>(S + ((ct + 1) * ngt + gtc) * 1024)[q * 64 + lane];
-        }
-        const u4v *im = img + buf * C::PU;
+        const u4v *im = img + islot * C::PU;
         // register v = 4 q' + r of lane (g, h) holds s[cell acc_row(v, h)][gene g]: A operand of C += S^T FU
+        f4v sc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sc[q] = __builtin_bit_cast(f4v, sbuf[sslot * 2048 + q * 64 + lane]);
         u4v a2[2][3];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -525,35 +563,44 @@ __global__ __launch_bounds__(512) void k_dn_col(const float *__restrict__ S, con
             for (int e = 0; e < 8; ++e) x[e] = sc[(8 * q + e) >> 2][(8 * q + e) & 3];
             split8(x, a2[q]);
         }
+        // the tile of s is in registers: its ring slot (and the image slot the work-group left at the last barrier) take
+        // the copies of the tile two ahead
+        issue(ct + 2, (islot == 0) ? 2 : islot - 1, sslot);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f16v dv;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) dv[v] = 0.f;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 u4v b[3];
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) b[sp] = im[((nt * 2 + q) * 3 + sp) * 64 + lane];
-                ORIANA_DN_MF6(dv, a2[q], b);
+                ORIANA_DN_MF6(dv[nt], a2[q], b);
             }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) cs[nt][v] += dv[v];
         }
         if (TAIL) {
-            const f4v *tails = reinterpret_cast<const f4v *>(im + C::P2);
+            // 16 blocks of 4 genes x 4 factors, one cell per instruction: A[b][i] = s of gene 4 (b % 8) + i (this lane's
+            // value), B[b][j] = FU[cell][KM + j]
+            const f4v *t2p = reinterpret_cast<const f4v *>(im + C::P2 + 32) + (h * 4 + (lane & 3)) * 4;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const f4v ft = tails[acc_row(v, h)];
-                const float s = sc[v >> 2][v & 3];
-                cta.x = fmaf(s, ft.x, cta.x); cta.y = fmaf(s, ft.y, cta.y);
-                cta.z = fmaf(s, ft.z, cta.z); cta.w = fmaf(s, ft.w, cta.w);
+            for (int q = 0; q < 4; ++q) {
+                const f4v t2 = t2p[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cta = __builtin_amdgcn_mfma_f32_4x4x1f32(sc[q][e], t2[e], cta, 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf ^= 1;
+        if (++since == COL_FLUSH) {      // 256 cells: leave the matrix core
+            since = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { cs[nt][v] += dv[nt][v]; dv[nt][v] = 0.f; }
+        }
+        wait_prev();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        islot = (islot == 2) ? 0 : islot + 1;
+        sslot ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last copies target LDS: they must land before the group ends)
     if (!active) return;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -561,14 +608,16 @@ __global__ __launch_bounds__(512) void k_dn_col(const float *__restrict__ S, con
         for (int v = 0; v < 16; ++v) {
             const int64_t gene = (int64_t)gt * 32 + acc_row(v, h);
             const int k = nt * 32 + c;
-            if (k < C::KM) atomicAdd(Cout + gene * Kp + k, cs[nt][v]);
+            if (k < C::KM) atomicAdd(Cout + gene * Kp + k, cs[nt][v] + dv[nt][v]);
         }
     if (TAIL) {
+        // lane 4 b + j holds, in register e, the tail sum of gene 4 (b % 8) + e and factor KM + j over its half's cells
         cta.x += __shfl_xor(cta.x, 32, 64); cta.y += __shfl_xor(cta.y, 32, 64);
         cta.z += __shfl_xor(cta.z, 32, 64); cta.w += __shfl_xor(cta.w, 32, 64);
         if (h == 0) {
-            float *p = Cout + ((int64_t)gt * 32 + c) * Kp + C::KM;
-            atomicAdd(p, cta.x); atomicAdd(p + 1, cta.y); atomicAdd(p + 2, cta.z); atomicAdd(p + 3, cta.w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(Cout + ((int64_t)gt * 32 + 4 * (lane >> 2) + e) * Kp + C::KM + (lane & 3), cta[e]);
         }
     }
 }
@@ -721,7 +770,7 @@ __global__ __launch_bounds__(256) void k_dn_metric(const uint16_t *__restrict__ 
 }
 
 template <int KC, int TAIL> constexpr int row_lds_bytes() { return 3 * Cfg<KC, TAIL>::PV * 16 + NW * 32 * TS * 4; }
-template <int KC, int TAIL> constexpr int col_lds_bytes() { return 2 * Cfg<KC, TAIL>::PU * 16; }
+template <int KC, int TAIL> constexpr int col_lds_bytes() { return 3 * Cfg<KC, TAIL>::PU * 16 + 2 * NW * 256 * 16; }
 
 template <typename Fn>
 static int set_lds(Fn fn, int bytes) {

@@ -25,6 +25,13 @@
 #else
 #define ORIANA_SYNC() __syncthreads()
 #endif
+// ORIANA_MASK_PAD: the K-vector reads and FMAs of a step run under the lanes' "this slot holds an entry" mask (padding
+// slots then cost no LDS bandwidth); analysis switch
+#ifdef ORIANA_MASK_PAD
+#define ORIANA_PAD_GUARD(cond) if (cond)
+#else
+#define ORIANA_PAD_GUARD(cond)
+#endif
 #if defined(ORIANA_ABLATE_NOSSTORE)
 #define ORIANA_S_STORE(dst, off, v) do { if ((v) == 12345.678f) (dst)[(off)] = (v); } while (0)   /* no scattered s stores */
 #else
@@ -1278,12 +1285,14 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
                     const int r = (int)qb_u32<U>(rvc);                                                \
                     const f4 *vrow = lds + r * ROW4;                                                  \
                     const f2 ss = {s, s};                                                             \
+                    ORIANA_PAD_GUARD(s != 0.f) {                                                      \
                     _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) {                               \
                         const f4 v = vrow[lidx[tt]];                                                  \
                         ACC[tt].xy = __builtin_elementwise_fma(ss, v.xy, ACC[tt].xy);                 \
                         ACC[tt].zw = __builtin_elementwise_fma(ss, v.zw, ACC[tt].zw);                 \
                     }                                                                                 \
                     if (TAIL) ACT = fmaf(s, tails[r * Im::TSTR + toff], ACT);                         \
+                    }                                                                                 \
                     /* step fence: one step's K-vector live at a time (both accumulator sets stay in registers) */ \
                     _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(ACC[tt]));  \
                     asm volatile("" : "+v"(svc), "+v"(rvc));                                          \

@@ -99,7 +99,7 @@ class FactorModel:
         elif _is_sparse_input(cmatrix):
             A = cmatrix._sparse if hasattr(cmatrix, '_sparse') else cmatrix
             X_host = A                     # the host-side initialisation reads it in sparse form
-            self.counts = engine.CountTiles.from_scipy(A, self.device, reduce_fn=rf)
+            self.counts = engine.CountTiles.from_scipy(A, self.device, reduce_fn=rf, dense_density=dd, n_total=n_total)
         else:
             X = cmatrix.as_array() if hasattr(cmatrix, 'as_array') else cmatrix
             if not isinstance(X, torch.Tensor):
@@ -158,7 +158,7 @@ class FactorModel:
 
     def _dense_density(self, dense_density, cmatrix, n_total, init=None):
         """The density threshold of the hybrid layout for this model, or None."""
-        if self.zi or self.sparse or isinstance(cmatrix, engine.CountTiles) or _is_sparse_input(cmatrix):
+        if self.zi or self.sparse or isinstance(cmatrix, engine.CountTiles):
             return None
         if isinstance(init, str) and init == 'nmf':      # the on-device NMF start walks the sliced layout only
             return None

@@ -44,6 +44,11 @@ class _ZIMixin:
         self._nzmask = torch.zeros(((n + 31) // 32) * max(m, 1), dtype=torch.int32, device=dev)
         call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._D_hat), n, m, stream_ptr())
         self._pd_sum_fresh = False
+        # non-zero counts per gene (local rows): the float32 sweep kernel counts p_d = float32(1 - 1e-10) = 1 at the non-zeros;
+        # the M-step takes the 1e-10 per entry back, as the reference's float64 mean has it (zigap.py:135, 158) -- a gene
+        # expressed in every cell then gets pi_d = 1 - 1e-10 (finite logit), not 1
+        self._nnz_gene = torch.zeros(m, dtype=torch.float64, device=dev)
+        call('oriana_colsum_wide_f32', ptr(self._nnz_gene), ptr(self._D_hat), n, m, stream_ptr())
         # float32 matrix-core path of the sweep (dense_f32.hip) and the D_hat V product it leaves for the next sweep,
         # valid while (D_hat, V_hat, S_hat) are the tensors it was formed from: _ver counts their writes
         self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
@@ -132,6 +137,7 @@ class _ZIMixin:
                 call('oriana_dropout_sweep_fused', ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
                      ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self._matrix_arith,
                      self.n, self.m, self.k, stream_ptr())
+                self._pd_sum.sub_(self._nnz_gene, alpha=1e-10)      # the non-zeros are 1 - 1e-10 each, not 1
             else:
                 DV = None
                 call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),

@@ -32,9 +32,9 @@ for cb in (0, cbm):
         t = run([[cb, 0, band]] * nw)
         print('cb=%d (%.0f slots/WG, %.1f iters/tile/slice) nWG=%4d: %.3f ms -> %.1f ns per slice-iteration per wave' % (cb, slots, slots / band / 16 / 64, nw, t, t * 1e6 / (slots / 16 / 64)))
 # the real work list
-t = run(ct.col_work.cpu().numpy().tolist())
-print('work list (%d items): %.3f ms' % (ct.col_work.shape[0], t))
-w = ct.col_work.cpu().numpy()
+t = run(ct.col_work_for(K).cpu().numpy().tolist())
+print('work list (%d items): %.3f ms' % (ct.col_work_for(K).shape[0], t))
+w = ct.col_work_for(K).cpu().numpy()
 work = np.array([per_tile[a:b, c].sum() for c, a, b in w])
 print('item slots: max %.3g mean %.3g; sum/256 = %.3g -> ideal time at the 256-WG rate' % (work.max(), work.mean(), work.sum() / 256))
 h = ct.host_arrays()

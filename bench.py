@@ -156,7 +156,7 @@ def main():
     gen = SyntheticCounts(n_total, m, K, seed=seed, device=dev, zero_inflation_level=z, row0=r0, n=n)
     dd = None
     if mname == 'GaP' and engine.dense_supported(K):
-        dd = engine.DENSE_DENSITY_DEFAULT if args.dense_density == 'auto' else (float(args.dense_density) or None)
+        dd = engine.auto_dense_density(n_total, m, K) if args.dense_density == 'auto' else (float(args.dense_density) or None)
     counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
                                            reduce_fn=(lambda t: odist.all_reduce_sum(t)) if world > 1 else None,
                                            dense_density=dd, n_total=n_total)
@@ -280,6 +280,13 @@ def main():
                          'fixup_ms': ks.get('fixup', 0.0),
                          # the responsibility kernels are bound on the CU side: VALU issue + LDS-return
                          # traffic, not HBM -- the same launches against those rates
+                         # what binds each kernel of the pass (counters under profiles/r03_*)
+                         'limiter_per_kernel': {k: v for k, v in {
+                             'row_pass': 'VALU issue + LDS return port (two lanes per row, 400 B of K-vector per slot)',
+                             'col_pass': 'LDS array bandwidth (1 FMA per 4 B read: ~150 B/clk/CU sustained)',
+                             'dense_row': 'matrix pipe + LDS operand reads + VALU (splits, s = x / den), which add up rather than overlap',
+                             'dense_col': 'matrix pipe + LDS operand reads + VALU (splits of s); HBM read of s (4 B per entry)',
+                             'dense_images': 'HBM (split operand images, (n + gd) K values)', 'fixup': 'rare (exact slow path)'}.items() if k in ks},
                          'limiter': ('valu+lds (see DESIGN.md section 4)' if not model.zi else
                                      'responsibility kernels: valu+lds (DESIGN.md section 4); dense ZI kernels: valu + matrix '
                                      'cores, which barely overlap (DESIGN.md section 10h)'),

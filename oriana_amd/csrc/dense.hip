@@ -167,29 +167,30 @@ __global__ __launch_bounds__(256) void k_scale_factor(float *__restrict__ Fout, 
 __global__ __launch_bounds__(256) void k_log_center(double *__restrict__ acc, const float *__restrict__ F,
                                                     const float *__restrict__ logF, const float *__restrict__ W,
                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
-    __shared__ double ssum[256];
-    __shared__ double scnt[256];
-    ssum[threadIdx.x] = 0.0;
-    scnt[threadIdx.x] = 0.0;
-    __syncthreads();
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row < r) {
-        const int64_t src = row_index ? (int64_t)row_index[row] : row;
-        for (int k = 0; k < K; ++k) {
+    // thread = (row group, factor): a factor's 1024 / RG rows of the block are summed in registers (coalesced across
+    // the factors), the row groups through LDS, one pair of float64 atomics per factor and block
+    __shared__ double ssum[256], scnt[256];
+    const int Kc = (K <= 64) ? 64 : (K <= 128) ? 128 : 256, RG = 256 / Kc;
+    const int k = threadIdx.x % Kc, rg = threadIdx.x / Kc;
+    double sum = 0.0, cnt = 0.0;
+    if (k < K) {
+        const int64_t r0 = (int64_t)blockIdx.x * 1024;
+        const int64_t r1 = (r0 + 1024 < r) ? r0 + 1024 : r;
+        for (int64_t row = r0 + rg; row < r1; row += RG) {
+            const int64_t src = row_index ? (int64_t)row_index[row] : row;
             const float f = F[row * Kp + k], l = logF[src * K + k];
             if (f > 1e-20f && fabsf(l) < 1e30f) {          // (a rejected row is the constant 1e-30: it never counts)
                 const double w = W ? (double)W[src * K + k] : 1.0;
-                if (w > 0.0 && w < 1e300) {
-                    atomicAdd(&ssum[k], w * (double)l);
-                    atomicAdd(&scnt[k], w);
-                }
+                if (w > 0.0 && w < 1e300) { sum += w * (double)l; cnt += w; }
             }
         }
     }
+    ssum[threadIdx.x] = sum;
+    scnt[threadIdx.x] = cnt;
     __syncthreads();
-    if ((int)threadIdx.x < K && scnt[threadIdx.x] > 0.0) {
-        atomicAdd(&acc[threadIdx.x], ssum[threadIdx.x]);
-        atomicAdd(&acc[K + threadIdx.x], scnt[threadIdx.x]);
+    if (rg == 0 && k < K) {
+        for (int g = 1; g < RG; ++g) { sum += ssum[g * Kc + k]; cnt += scnt[g * Kc + k]; }
+        if (cnt > 0.0) { atomicAdd(&acc[k], sum); atomicAdd(&acc[K + k], cnt); }
     }
 }
 
@@ -371,7 +372,7 @@ extern "C" int oriana_log_center(double *acc, const float *F, const float *logF,
     if (e != hipSuccess) return -1000 - (int)e;
     if (r == 0) return 0;
     if (!F || !logF) return ORIANA_EINVAL;
-    hipLaunchKernelGGL(k_log_center, dim3((unsigned)((r + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, F, logF,
+    hipLaunchKernelGGL(k_log_center, dim3((unsigned)((r + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, acc, F, logF,
                        W, row_index, r, (int)K, (int)Kp);
     ORIANA_LAUNCH_CHECK();
     return 0;

@@ -451,11 +451,21 @@ DENSE_DENSITY_DEFAULT = 0.2
 
 def dense_density_default():
     e = os.environ.get('ORIANA_DENSE_DENSITY')
-    if e is None or e == '':
+    if e is None or e == '' or e == 'auto':
         return DENSE_DENSITY_DEFAULT
     if e.lower() in ('0', 'off', 'none', 'no'):
         return None
     return float(e)
+
+
+def auto_dense_density(n_total, m, K):
+    """The threshold 'auto' stands for: the default above for a K the dense kernels are compiled for and a matrix of at
+    least 2e8 entries (below that a sweep is a few dozen launches of microseconds of work each, and the five extra
+    launches of the hybrid layout cost more than its kernels save), None otherwise."""
+    dd = dense_density_default()
+    if not dd or not dense_supported(K) or float(n_total) * float(m) < 2e8:
+        return None
+    return float(dd)
 
 
 class ZWorkspace:

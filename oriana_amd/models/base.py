@@ -64,9 +64,9 @@ class FactorModel:
     reference_quirks : reproduce zigap.py:94 (``D_hat[i, k]``) -- see SURVEY.md 8(a) policy.
     dense_density : pCMF only -- genes expressed in at least this share of the cells are evaluated densely on the bf16
         matrix cores in float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip).
-        ``'auto'``: engine.DENSE_DENSITY_DEFAULT (or the environment's ORIANA_DENSE_DENSITY; ``0`` / ``off`` disables)
-        for matrices of at least 4096 cells and a K the dense kernels are compiled for; ignored for a prebuilt
-        ``engine.CountTiles`` (its own layout is used).
+        ``'auto'``: engine.auto_dense_density -- engine.DENSE_DENSITY_DEFAULT (or the environment's ORIANA_DENSE_DENSITY;
+        ``0`` / ``off`` disables) for matrices of at least 2e8 entries and a K the dense kernels are compiled for; ignored
+        for a prebuilt ``engine.CountTiles`` (its own layout is used).
     """
 
     zi = False
@@ -162,14 +162,16 @@ class FactorModel:
             return None
         if isinstance(init, str) and init == 'nmf':      # the on-device NMF start walks the sliced layout only
             return None
-        dd = engine.dense_density_default() if isinstance(dense_density, str) and dense_density == 'auto' else dense_density
-        if not dd or not engine.dense_supported(self.k):
-            return None
         shape = getattr(cmatrix, 'shape', None)
         rows = int(n_total) if n_total is not None else (int(shape[0]) if shape is not None else 0)
-        if isinstance(dense_density, str) and rows < 4096:
+        cols = int(shape[1]) if shape is not None else 0
+        if isinstance(dense_density, str):
+            if dense_density != 'auto':
+                raise ValueError("dense_density must be 'auto', a density in (0, 1] or 0 / None")
+            return engine.auto_dense_density(rows, cols, self.k)
+        if not dense_density or not engine.dense_supported(self.k):
             return None
-        return float(dd)
+        return float(dense_density)
 
     # ---- initial shapes -------------------------------------------------------------------------
     def _initial_shapes(self, X_host, init):

@@ -117,3 +117,46 @@ def test_count_matrix_surface(tmp_path):
     assert np.array_equal(s.T.as_array(), X.T)
     with pytest.raises(DatatypeException):
         CountMatrix([[1, 2], [3, 4]])
+
+
+def test_hybrid_gene_order_rules():
+    """CountTiles.dense_order: dense genes first (density >= threshold, every count an integer below 65535), by
+    decreasing non-zero count, cut to a multiple of 32; the rest in decreasing order; a permutation in all cases."""
+    import torch
+    from oriana_amd.engine import CountTiles
+    g = torch.Generator().manual_seed(3)
+    m, n = 200, 1000
+    nnz = torch.randint(0, n + 1, (m,), generator=g)
+    nnz[:5] = 0
+    bad = torch.zeros(m, dtype=torch.int64)
+    bad[torch.argsort(nnz, descending=True)[:3]] = 1                       # the three densest genes hold a non-integer count
+    order, gd = CountTiles.dense_order(nnz, n, bad, 0.5)
+    assert sorted(order.tolist()) == list(range(m))
+    cand = ((nnz >= 0.5 * n) & (bad == 0)).sum().item()
+    assert gd == (cand // 32) * 32 and gd > 0
+    head, rest = order[:gd], order[gd:]
+    assert (nnz[head] >= 0.5 * n).all() and (bad[head] == 0).all()
+    assert (nnz[head][:-1] >= nnz[head][1:]).all() and (nnz[rest][:-1] >= nnz[rest][1:]).all()
+    # every candidate that was cut off sorts before any sparser gene, the disqualified ones stay in the sliced part
+    assert set(torch.nonzero(bad).flatten().tolist()) <= set(rest.tolist())
+    # fewer than 32 candidates: no dense block, plain decreasing order
+    order0, gd0 = CountTiles.dense_order(nnz, n, bad, 0.999)
+    assert gd0 == 0 and (nnz[order0][:-1] >= nnz[order0][1:]).all()
+    # empty genes never qualify, whatever the threshold
+    order1, gd1 = CountTiles.dense_order(torch.zeros(64, dtype=torch.int64), n, torch.zeros(64, dtype=torch.int64), 0.0)
+    assert gd1 == 0 and sorted(order1.tolist()) == list(range(64))
+
+
+def test_hybrid_auto_threshold(monkeypatch):
+    """'auto': the measured break-even for a factor count the dense kernels exist for and >= 2e8 entries; the
+    ORIANA_DENSE_DENSITY switch overrides the value or turns the layout off."""
+    from oriana_amd import engine
+    monkeypatch.delenv('ORIANA_DENSE_DENSITY', raising=False)
+    assert engine.auto_dense_density(1_000_000, 30_000, 100) == engine.DENSE_DENSITY_DEFAULT
+    assert engine.auto_dense_density(10_000, 2_000, 20) is None            # configs[1]: launch-bound, stays sliced
+    assert engine.auto_dense_density(1_000_000, 30_000, 112) is None       # no dense kernel above Kp = 100
+    assert engine.dense_supported(5) and engine.dense_supported(100) and not engine.dense_supported(101)
+    monkeypatch.setenv('ORIANA_DENSE_DENSITY', '0.3')
+    assert engine.auto_dense_density(1_000_000, 30_000, 100) == 0.3
+    monkeypatch.setenv('ORIANA_DENSE_DENSITY', 'off')
+    assert engine.auto_dense_density(1_000_000, 30_000, 100) is None

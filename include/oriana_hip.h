@@ -128,6 +128,19 @@ int oriana_factor_prep(float *F, float *mu, const float *logF, const float *mask
 int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
                             const int32_t *row_index_u, const int32_t *row_index_v,
                             int64_t n, int64_t m, int64_t K, float *scratch, void *stream);
+/* The same with a list of buffers that the second launch zero-fills on the side (the outputs and scratch the passes of
+ * a sweep accumulate into -- Z_i, Z_j, C, tile_flag, the float64 column sums): on a small matrix (configs[1]) the fill
+ * kernels were a seventh of the sweep.  Each entry: a 4-byte aligned pointer and a byte count that is a multiple of 4
+ * (0 = unused).  clr may be NULL. */
+#define ORIANA_CLEAR_MAX 8
+typedef struct oriana_clear_list {
+    void   *ptr[ORIANA_CLEAR_MAX];
+    int64_t bytes[ORIANA_CLEAR_MAX];
+} oriana_clear_list;
+int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                                  const int32_t *row_index_u, const int32_t *row_index_v,
+                                  int64_t n, int64_t m, int64_t K, float *scratch, const oriana_clear_list *clr,
+                                  void *stream);
 int64_t oriana_prep_scratch_bytes(void);   /* includes 4096 bytes for the log-sum centres at oriana_prep_center_offset() */
 int64_t oriana_prep_center_offset(void);
 
@@ -153,6 +166,15 @@ int oriana_row_pass(const oriana_counts *cm,
                     float *s_rs,            /* [rslots] out: s_ij, row-side slots, or NULL */
                     int32_t *tile_flag,     /* [nrb*ncb] out: 1 if the tile holds slow-path entries (zero it first) */
                     int64_t K, void *stream);
+
+/* The plain row pass (w_nz = NULL, no row-side copy of s) with the gene tiles of every row block split over
+ * `gene_splits` work-groups: a row block is one work-group, so a matrix of 10,000 cells (configs[1]) ran the pass on 40
+ * of the 256 CUs.  R is then (gene_splits, n, Kp): every group stores the row sums of its gene range in its own slab
+ * (no atomics, nothing to clear); oriana_finalize_slabs / oriana_gamma_update_finalize add the slabs up.
+ * oriana_row_pass_gene_splits: the split that fills the chip (1 from 256 row-side work-groups on). */
+int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t K);
+int oriana_row_pass_split(const oriana_counts *cm, const float *FU, const float *FV, float *R, float *s_cs,
+                          int32_t *tile_flag, int64_t K, int64_t gene_splits, void *stream);
 
 /* The row pass of the sparse models with the S_hat-weighted sums folded in (sparse_gap.py:88-95): the dot product
  * runs against FV (= exp-shifted E[log V] masked by S_tilde), the accumulation against FV2 (= FV * S_hat), both staged
@@ -248,6 +270,10 @@ int oriana_dense_metric(const oriana_dense *d, const double *U, const double *V,
 int oriana_finalize(float *Z, const float *F, const float *R, const float *mul, const int32_t *row_index,
                     int64_t r, int64_t K, int accumulate, void *stream);
 
+/* Z[o,k] += F[i,k] * (R[0][i,k] + ... + R[nslab-1][i,k]) -- R = (nslab, r, Kp) as oriana_row_pass_split leaves it. */
+int oriana_finalize_slabs(float *Z, const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                          int64_t r, int64_t K, void *stream);
+
 /* Slow path (exact reference arithmetic) for the entries flagged by oriana_row_pass.
  * variant bit 0: S_tilde / S_hat present (sparse models); bit 1: D_hat weights (w_nz);
  * bit 2: reference quirk zigap.py:94 (dq = D_hat[:, :K] dense (n, K)).
@@ -331,11 +357,28 @@ int oriana_gamma_update(double *a1, double *a2, double *E, float *Elog,
                         const double *rate_vec, const double *rate_mat, const float *rmul,
                         int64_t r, int64_t K, void *stream);
 
+/* The same update with the last step of the responsibility pass folded in (pCMF, gap.py:79-80 + 96-110): rows are walked
+ * in PACKED order p, Z[o,k] += F[p,k] * sum_s R[s][p,k] with o = row_index ? row_index[p] : p (what oriana_finalize_slabs
+ * does; R = (nslab, r, Kp); Z stays a complete output) and a1 = prior1 + Z, a2 = prior2 + rate_vec at once -- one launch
+ * and one pass over Z less per side. */
+int oriana_gamma_update_finalize(double *a1, double *a2, double *E, float *Elog,
+                                 double *colsum_E, double *colsum_Elog,
+                                 const double *prior1, const double *prior2,
+                                 float *Z, const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                                 const double *rate_vec, int64_t r, int64_t K, void *stream);
+
 /* M-step for one Gamma node (gap.py:117-129; utils.py:39-51):
  *   p1 = max(1e-15, nan_to_num(inverse_digamma(log(p2) + f32(colsum_Elog / count))))
  *   p2 = max(1e-15, nan_to_num(p1 / (colsum_E / count)))            (K-vectors, f64, in place) */
 int oriana_mstep_gamma(double *p1, double *p2, const double *colsum_E, const double *colsum_Elog,
                        double count, int64_t K, void *stream);
+
+/* Both Gamma nodes in one launch.  keep_v (2K values or NULL): copy of the V side's column sums {sum E, sum Elog} --
+ * a sweep that accumulates them in scratch (cleared with the other scratch of the sweep) keeps them here for the next
+ * sweep's cell-side rate, sum_j V_hat (gap.py:98). */
+int oriana_mstep_gamma_pair(double *p1u, double *p2u, const double *colsum_E_u, const double *colsum_Elog_u, double count_u,
+                            double *p1v, double *p2v, const double *colsum_E_v, const double *colsum_Elog_v, double count_v,
+                            double *keep_v, int64_t K, void *stream);
 
 /* Column sums of a dense (r, K) f64 matrix, optionally times an f32 (r, K) multiplier, added
  * into out[K] (zero it first) -- `V_hat.sum(axis=0)`, gap.py:98. */

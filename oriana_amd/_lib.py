@@ -29,6 +29,11 @@ class OrianaDense(ctypes.Structure):
     _fields_ = [('n', c_int64), ('gd', c_int64), ('nct', c_int64), ('x', c_void_p)]
 
 
+class OrianaClearList(ctypes.Structure):
+    """struct oriana_clear_list (include/oriana_hip.h): up to 8 buffers zero-filled by the factor preparation's launch."""
+    _fields_ = [('ptr', c_void_p * 8), ('bytes', c_int64 * 8)]
+
+
 _P = c_void_p
 _I = c_int64
 _SIGS = {
@@ -39,8 +44,11 @@ _SIGS = {
     'oriana_pack_fill': (c_int, [_P, c_int, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'oriana_factor_prep': (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_factor_prep_pair': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'oriana_factor_prep_pair_clear': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, ctypes.POINTER(OrianaClearList), _P]),
     'oriana_prep_scratch_bytes': (_I, []),
     'oriana_row_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_row_pass_gene_splits': (_I, [ctypes.POINTER(OrianaCounts), _I]),
+    'oriana_row_pass_split': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
     'oriana_row_pass_masked': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
@@ -56,6 +64,7 @@ _SIGS = {
     'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_dense_metric': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),
+    'oriana_finalize_slabs': (c_int, [_P, _P, _P, _I, _P, _I, _I, _P]),
     'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _I, c_int, _P]),
     'oriana_zq_workspace_bytes': (c_int64, [_I, _I, _I, _I]),
@@ -65,6 +74,8 @@ _SIGS = {
     'oriana_zq_sparse_zigap_f32': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     'oriana_gamma_update': (c_int, [_P] * 13 + [_I, _I, _P]),
     'oriana_mstep_gamma': (c_int, [_P, _P, _P, _P, c_double, _I, _P]),
+    'oriana_gamma_update_finalize': (c_int, [_P] * 11 + [_I, _P, _P, _I, _I, _P]),
+    'oriana_mstep_gamma_pair': (c_int, [_P, _P, _P, _P, c_double, _P, _P, _P, _P, c_double, _P, _I, _P]),
     'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),
     'oriana_dropout_update': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_dropout_update_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -131,8 +142,19 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """The HIP stream torch currently launches on (of the current device), as an integer handle.  Called once per
+    launch: torch.cuda.current_stream() builds a Stream object and resolves the device index in Python (8 us -- more
+    than a small kernel runs); the raw getter behind it is a single C call."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -124,8 +124,15 @@ __device__ inline double trigamma_f64(double x) {
 __device__ inline double inverse_digamma_f64(double y) {
     const double psi1 = -0.5772156649015329;   // digamma(1)
     double x = (y >= -2.22) ? exp(y) + 0.5 : -1.0 / (y - psi1);
+    // (five Newton steps, utils.py:47-50; a step that no longer moves x ends the loop -- the remaining ones would
+    //  reproduce it: each costs a dozen dependent float64 divisions, and the M-step is a single short launch)
     #pragma unroll 1
-    for (int it = 0; it < 5; ++it) x -= (digamma_f64(x) - y) / trigamma_f64(x);
+    for (int it = 0; it < 5; ++it) {
+        const double xn = x - (digamma_f64(x) - y) / trigamma_f64(x);
+        const bool same = xn == x;
+        x = xn;
+        if (same) break;
+    }
     return x;
 }
 

@@ -18,6 +18,8 @@
 // data-dependent branch.  No MFMA: the work is a sampled dot product per non-zero plus two scaled
 // vector adds over the sparse support of X, not a dense contraction.
 #include "common.h"
+#include <string.h>
+#include <stdlib.h>
 
 // Ablation switches for kernel analysis builds (never defined in the shipped library).
 #ifdef ORIANA_ABLATE_NOBARRIER
@@ -102,7 +104,7 @@ __device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stat
 constexpr int STATS_MAX_BLOCKS = 1024;                 // per side
 __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, const float *__restrict__ logU, int64_t n,
                                                    const float *__restrict__ logV, const float *__restrict__ maskV,
-                                                   int64_t m, int K, int nbu) {
+                                                   int64_t m, int K, int nbu, int lane_rows) {
     __shared__ float bs[4], bq[4], bc[4];
     __shared__ bool last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -112,6 +114,23 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
     const int64_t r = vside ? m : n;
     const int64_t b0 = vside ? (int64_t)blockIdx.x - nbu : blockIdx.x, nb = vside ? (int64_t)gridDim.x - nbu : nbu;
     float sum = 0.f, sq = 0.f, cnt = 0.f;
+    if (lane_rows) {
+        // narrow rows (K <= 32): one LANE per row -- 256 rows per group in flight at once instead of 4
+        for (int64_t row = b0 * 256 + threadIdx.x; row < r; row += nb * 256) {
+            const float *l = logF + row * K;
+            const float *mk = mask ? mask + row * K : nullptr;
+            float mx = -INFINITY;
+            bool bad = false, any_on = false;
+            #pragma unroll 4
+            for (int k = 0; k < K; ++k) {
+                const float v = l[k];
+                const bool on = mk ? (mk[k] != 0.0f) : true;
+                if (on) { any_on = true; if (v != v) bad = true; mx = fmaxf(mx, v); }
+            }
+            if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; sq += mx * mx; cnt += 1.f; }
+        }
+        sum = wave_sum(sum); sq = wave_sum(sq); cnt = wave_sum(cnt);
+    } else
     for (int64_t row = b0 * 4 + w; row < r; row += nb * 4) {
         const float *l = logF + row * K;
         const float *mk = mask ? mask + row * K : nullptr;
@@ -214,15 +233,32 @@ __global__ __launch_bounds__(256) void k_factor_prep(float *__restrict__ F, floa
     factor_prep_row(F, mu_out, logF, mask, row_index, r, K, Kp, nullptr, 0, blockIdx.x);
 }
 
-// both sides in one launch (blocks [0, nbu): FU, the others: FV), limits from `stats`
+// both sides in one launch (blocks [0, nbu): FU, the next nbv: FV), limits from `stats`; the blocks after those
+// zero-fill the buffers of `clr` (the outputs and scratch a sweep accumulates into: one launch instead of one fill
+// kernel per buffer, which is most of a sweep's time on a small matrix)
 __global__ __launch_bounds__(256) void k_factor_prep_pair(float *__restrict__ FU, float *__restrict__ FV,
                                                           const float *__restrict__ logU, const float *__restrict__ logV,
                                                           const float *__restrict__ maskV,
                                                           const int32_t *__restrict__ riu, const int32_t *__restrict__ riv,
-                                                          int64_t n, int64_t m, int K, int Kp, int nbu,
-                                                          const float *__restrict__ stats) {
-    if ((int)blockIdx.x < nbu) factor_prep_row(FU, nullptr, logU, nullptr, riu, n, K, Kp, stats, 0, blockIdx.x);
-    else factor_prep_row(FV, nullptr, logV, maskV, riv, m, K, Kp, stats, 1, (int64_t)blockIdx.x - nbu);
+                                                          int64_t n, int64_t m, int K, int Kp, int nbu, int nbv,
+                                                          const float *__restrict__ stats, oriana_clear_list clr) {
+    if ((int)blockIdx.x < nbu) { factor_prep_row(FU, nullptr, logU, nullptr, riu, n, K, Kp, stats, 0, blockIdx.x); return; }
+    if ((int)blockIdx.x < nbu + nbv) { factor_prep_row(FV, nullptr, logV, maskV, riv, m, K, Kp, stats, 1, (int64_t)blockIdx.x - nbu); return; }
+    const int64_t cb = (int64_t)blockIdx.x - nbu - nbv, ncl = (int64_t)gridDim.x - nbu - nbv;
+    #pragma unroll 1
+    for (int e = 0; e < ORIANA_CLEAR_MAX; ++e) {
+        uint32_t *p = static_cast<uint32_t *>(clr.ptr[e]);
+        const int64_t words = clr.bytes[e] >> 2;
+        if (!p || words <= 0) continue;
+        if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const int64_t quads = words >> 2;
+            uint4 *p4 = reinterpret_cast<uint4 *>(p);
+            for (int64_t i = cb * 256 + threadIdx.x; i < quads; i += ncl * 256) p4[i] = uint4{0u, 0u, 0u, 0u};
+            for (int64_t i = quads * 4 + cb * 256 + threadIdx.x; i < words; i += ncl * 256) p[i] = 0u;
+        } else {
+            for (int64_t i = cb * 256 + threadIdx.x; i < words; i += ncl * 256) p[i] = 0u;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -358,8 +394,12 @@ template <int NTHREADS>
 __device__ __forceinline__ void flush_block(const float *ldsf, float *dst, int nfloats, bool plain, int tid) {
     for (int idx = tid; idx < nfloats; idx += NTHREADS) {
         const float v = ldsf[idx];
+#ifdef ORIANA_ABL_NOFLUSH
+        if (v == 1.2345f) dst[idx] = v;
+#else
         if (plain) dst[idx] = v;
         else if (v != 0.f) atomicAdd(dst + idx, v);
+#endif
     }
 }
 
@@ -437,7 +477,10 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
         rowfilled = !(group_max<G>(fm) == 1.0f);
     }
 
-    for (int64_t cb = 0; cb < cm.ncb; ++cb) {
+    // gridDim.y > 1 (oriana_row_pass_split, short matrices): this group takes the gene tiles [cb0, cb1) of its row
+    // block and stores its row sums in slab blockIdx.y of R
+    const int64_t cb0 = (int64_t)blockIdx.y * cm.ncb / gridDim.y, cb1 = ((int64_t)blockIdx.y + 1) * cm.ncb / gridDim.y;
+    for (int64_t cb = cb0; cb < cb1; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
         const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
         const int niter = __builtin_amdgcn_readfirstlane((int)((s1 - s0) >> 6));
@@ -552,9 +595,10 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n && !SROW) {
+        float *Rs = R + (int64_t)blockIdx.y * cm.n * KP;
         #pragma unroll
-        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + choff[t]] = acc[t];
-        if (TAIL) R[row * KP + TOFF + q] = acct;
+        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(Rs)[row * KP4 + choff[t]] = acc[t];
+        if (TAIL) Rs[row * KP + TOFF + q] = acct;
     }
 }
 
@@ -870,15 +914,20 @@ __global__ __launch_bounds__(256) void k_col_reduce(float *__restrict__ C, const
 __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const float *__restrict__ F,
                                                   const float *__restrict__ R, const float *__restrict__ mul,
                                                   const int32_t *__restrict__ row_index, int64_t r, int K, int Kp,
-                                                  int accumulate) {
+                                                  int accumulate, int nslab) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= r * K) return;
     const int64_t row = idx / K;
     const int k = (int)(idx - row * K);
     const int64_t o = (row_index ? (int64_t)row_index[row] : row) * K + k;
-    float v = F[row * Kp + k] * R[row * Kp + k];
+    const float f = F[row * Kp + k];
+    float rr = R[row * Kp + k];
+    for (int sl = 1; sl < nslab; ++sl) rr += R[((int64_t)sl * r + row) * Kp + k];      // oriana_row_pass_split
+    float v = f * rr;
     if (mul) v *= mul[o];
-    Z[o] = (accumulate ? Z[o] + v : v) + 0.0f;          // (+ 0: a dead factor row is -0.0; the outputs carry +0)
+    // (+ 0: a dead factor row is -0.0; the outputs carry +0.  The accumulating form without a multiplier is spelled as
+    //  ONE fused multiply-add: k_gamma_update<true> folds this statement in and must round the same way)
+    Z[o] = (accumulate ? (mul ? Z[o] + v : fmaf(f, rr, Z[o])) : v) + 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1075,7 +1124,9 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         rowfilled = !(fm == 1.0f);
     }
 
-    for (int64_t cb = 0; cb < cm.ncb; ++cb) {
+    // gridDim.y > 1: gene tiles [cb0, cb1) of the row block, row sums stored in slab blockIdx.y of R (see k_row_pass)
+    const int64_t cb0 = (int64_t)blockIdx.y * cm.ncb / gridDim.y, cb1 = ((int64_t)blockIdx.y + 1) * cm.ncb / gridDim.y;
+    for (int64_t cb = cb0; cb < cb1; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
         const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
         const int nit = (int)((s1 - s0) >> 6);                    // iterations of this half wave's slice
@@ -1172,9 +1223,10 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n && !SROW) {
+        float *Rs = R + (int64_t)blockIdx.y * cm.n * KP;
         #pragma unroll
-        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(R)[row * KP4 + gchunk(lane, t)] = acc[t];
-        if (TAIL) *reinterpret_cast<f2 *>(R + row * KP + 96 + 2 * q) = acct;
+        for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(Rs)[row * KP4 + gchunk(lane, t)] = acc[t];
+        if (TAIL) *reinterpret_cast<f2 *>(Rs + row * KP + 96 + 2 * q) = acct;
     }
 }
 
@@ -1412,6 +1464,249 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
 }
 
 
+// ==========================================================================================
+// Narrow factor rows (Kp <= 32, i.e. K <= 32 -- configs[1] has K = 20): ONE LANE PER ROW.
+// The kernels above give a matrix row 4 lanes, each holding Kp / 4 factors: a step of a wave covers 16 slots, and for
+// K = 20 only 5 of its ~50 instructions are FMAs -- the rest (record decode, DPP broadcasts, the 4-lane sum, the
+// reciprocal, the store) is per STEP, whatever K is.  Here a lane owns a whole row of the row block (a whole gene of
+// the column tile): it keeps the Kp factors and the Kp accumulators in registers, reads a whole factor row of the
+// other side from LDS per slot and needs no cross-lane traffic at all; a step of a wave covers 64 slots.  A wave takes
+// four 16-row slices of the sliced layout at once (lanes 16a .. 16a+15 = slice 4w + a), a work-group of 256 threads a
+// row block (a column tile).  The LDS image has an ODD row stride in 16-byte units, so that the lanes' reads of
+// random rows spread over the banks.
+// ==========================================================================================
+namespace narrow {
+
+template <int KP>
+struct Geo {
+    static constexpr int KP4 = KP / 4;
+    static constexpr int ST4 = KP4 | 1;                  // image row stride in float4 (odd)
+    static constexpr size_t bytes() { return (size_t)TILE * ST4 * sizeof(f4); }
+};
+
+// 256 rows x KP4 float4 of F (rows beyond `rows_total` read as 0), as registers of 256 threads
+template <int KP>
+struct Image {
+    static constexpr int KP4 = Geo<KP>::KP4, ST4 = Geo<KP>::ST4;
+    f4 v[KP4];
+    __device__ __forceinline__ void load(const float *__restrict__ F, int64_t row0, int64_t rows_total, int tid) {
+        #pragma unroll
+        for (int j = 0; j < KP4; ++j) {
+            const int id = tid + j * 256;                // chunk id inside the tile: row = id / KP4
+            const int r = id / KP4;
+            v[j] = (row0 + r < rows_total) ? reinterpret_cast<const f4 *>(F)[row0 * KP4 + id] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void store(f4 *lds, int tid) const {
+        #pragma unroll
+        for (int j = 0; j < KP4; ++j) {
+            const int id = tid + j * 256;
+            const int r = id / KP4, c = id - r * KP4;
+            lds[r * ST4 + c] = v[j];
+        }
+    }
+};
+
+__device__ __forceinline__ int wave_max_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// row pass (plain variant: no weights, no row-side copy of s); gridDim.y = gene-tile splits (slabs of R)
+template <int KP>
+__global__ __launch_bounds__(256) void k_row_pass_narrow(oriana_counts cm, const float *__restrict__ FU,
+                                                         const float *__restrict__ FV, float *__restrict__ R,
+                                                         float *__restrict__ s_cs, int32_t *__restrict__ tile_flag) {
+    constexpr int KP4 = Geo<KP>::KP4, ST4 = Geo<KP>::ST4;
+    constexpr int PD = 3;                                // record prefetch depth (iterations)
+    extern __shared__ f4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sl = wave * 4 + (lane >> 4), g = lane & 15;
+    const int64_t rb = blockIdx.x;
+    const int64_t row = rb * TILE + sl * 16 + g;
+    f4 fu[KP4], acc[KP4];
+    #pragma unroll
+    for (int c = 0; c < KP4; ++c) {
+        acc[c] = f4{0.f, 0.f, 0.f, 0.f};
+        fu[c] = (row < cm.n) ? reinterpret_cast<const f4 *>(FU)[row * KP4 + c] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t cb0 = (int64_t)blockIdx.y * cm.ncb / gridDim.y, cb1 = ((int64_t)blockIdx.y + 1) * cm.ncb / gridDim.y;
+    Image<KP> img;
+    if (cb0 < cb1) img.load(FV, cb0 * TILE, cm.m, tid);
+    for (int64_t cb = cb0; cb < cb1; ++cb) {
+        const int64_t t = rb * cm.ncb + cb;
+        const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
+        const int niter = (int)((s1 - s0) >> 6);                           // of this lane's slice
+        const int nwave = __builtin_amdgcn_readfirstlane(wave_max_i(niter));
+        // this lane's four records of iteration 0 (slots 4g .. 4g+3 of the slice's 64-slot iterations)
+        const uint4 *recp = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned long long *>(cm.rowrec) +
+                                                            cm.roff[t] + s0 + g * 4);
+        float *sdst = s_cs + cm.coff[t];
+        const uint32_t dummy = cm.cslice[t * 17 + 16] + lane;              // write-only slot of the tile
+        uint4 qa[PD], qb[PD];
+        #pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            qa[d] = uint4{0u, 0u, 0u, 0u}; qb[d] = uint4{0u, 0u, 0u, 0u};
+            if (d < niter) { qa[d] = recp[(int64_t)d * 32]; qb[d] = recp[(int64_t)d * 32 + 1]; }
+        }
+        ORIANA_SYNC();                                                     // everybody is done with the previous image
+        img.store(lds, tid);
+        ORIANA_SYNC();
+        if (cb + 1 < cb1) img.load(FV, (cb + 1) * TILE, cm.m, tid);         // the next image: in flight during the loop
+        bool bad = false;
+        // The factor row of a slot is read from LDS ONE STEP AHEAD of its use (vn while v is consumed): a short matrix
+        // gives a SIMD a single wave, whose time is the chain LDS read -> dot product -> reciprocal -> accumulate.
+        f4 v[KP4];
+        {
+            const f4 *vrow = lds + ((qa[0].y >> 16) & 0xFFu) * ST4;
+            #pragma unroll
+            for (int c = 0; c < KP4; ++c) v[c] = vrow[c];
+        }
+        for (int it = 0; it < nwave; ++it) {
+            const uint4 ra = qa[0], rbq = qb[0];
+            #pragma unroll
+            for (int d = 0; d + 1 < PD; ++d) { qa[d] = qa[d + 1]; qb[d] = qb[d + 1]; }
+            qa[PD - 1] = uint4{0u, 0u, 0u, 0u}; qb[PD - 1] = uint4{0u, 0u, 0u, 0u};
+            if (it + PD < niter) { qa[PD - 1] = recp[(int64_t)(it + PD) * 32]; qb[PD - 1] = recp[(int64_t)(it + PD) * 32 + 1]; }
+            // (a lane past the end of its own slice holds zero records: x = 0 = padding, image row 0)
+#define ORIANA_NROW_STEP(XB, BM, BMNEXT)                                                              \
+            {                                                                                         \
+                f4 vn[KP4];                                                                           \
+                {                                                                                     \
+                    const f4 *nrow = lds + (((BMNEXT) >> 16) & 0xFFu) * ST4;                          \
+                    _Pragma("unroll") for (int c = 0; c < KP4; ++c) vn[c] = nrow[c];                  \
+                }                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                    \
+                const float x = __uint_as_float(XB);                                                  \
+                const uint32_t bm = (BM);                                                             \
+                const bool valid = (x != 0.f);                                                        \
+                f2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};                                                \
+                _Pragma("unroll") for (int c = 0; c < KP4; ++c) {                                     \
+                    d01 = __builtin_elementwise_fma(fu[c].xy, v[c].xy, d01);                          \
+                    d23 = __builtin_elementwise_fma(fu[c].zw, v[c].zw, d23);                          \
+                }                                                                                     \
+                const f2 dd = d01 + d23;                                                              \
+                const float den = dd.x + dd.y;                                                        \
+                const bool ok = den >= DEN_MIN;              /* false for 0, tiny and NaN */          \
+                const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;                 \
+                const f2 ss = {s, s};                                                                 \
+                _Pragma("unroll") for (int c = 0; c < KP4; ++c) {                                     \
+                    acc[c].xy = __builtin_elementwise_fma(ss, v[c].xy, acc[c].xy);                    \
+                    acc[c].zw = __builtin_elementwise_fma(ss, v[c].zw, acc[c].zw);                    \
+                }                                                                                     \
+                const bool slow = valid && !ok;              /* NaN = "evaluate me exactly" */        \
+                bad = bad || slow;                                                                    \
+                ORIANA_S_STORE(sdst, valid ? (bm & 0xFFFFu) : dummy, slow ? NAN : s);                 \
+                _Pragma("unroll") for (int c = 0; c < KP4; ++c) v[c] = vn[c];                         \
+            }
+            ORIANA_NROW_STEP(ra.x, ra.y, ra.w)
+            ORIANA_NROW_STEP(ra.z, ra.w, rbq.y)
+            ORIANA_NROW_STEP(rbq.x, rbq.y, rbq.w)
+            ORIANA_NROW_STEP(rbq.z, rbq.w, qa[0].y)
+#undef ORIANA_NROW_STEP
+        }
+        if (__any(bad) && lane == 0) tile_flag[t] = 1;
+    }
+    if (row < cm.n) {
+        float *Rs = R + (int64_t)blockIdx.y * cm.n * KP;
+        #pragma unroll
+        for (int c = 0; c < KP4; ++c) reinterpret_cast<f4 *>(Rs)[row * KP4 + c] = acc[c];
+    }
+}
+
+// column pass: one column tile per work item (work list of width 1, or grid.y row bands), C += with float atomics
+template <int KP>
+__global__ __launch_bounds__(256) void k_col_pass_narrow(oriana_counts cm, const float *__restrict__ s_cs,
+                                                         const float *__restrict__ Gm, float *__restrict__ C,
+                                                         const int32_t *__restrict__ work, int64_t rb_per_band) {
+    constexpr int KP4 = Geo<KP>::KP4, ST4 = Geo<KP>::ST4;
+    constexpr int PD = 3;
+    extern __shared__ f4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sl = wave * 4 + (lane >> 4), g = lane & 15;
+    int64_t cb, rb0, rb1;
+    if (work) {
+        cb = work[(int64_t)blockIdx.x * 3 + 0]; rb0 = work[(int64_t)blockIdx.x * 3 + 1]; rb1 = work[(int64_t)blockIdx.x * 3 + 2];
+    } else {
+        cb = blockIdx.x;
+        rb0 = (int64_t)blockIdx.y * rb_per_band;
+        rb1 = (rb0 + rb_per_band < cm.nrb) ? rb0 + rb_per_band : cm.nrb;
+    }
+    f4 acc[KP4];
+    #pragma unroll
+    for (int c = 0; c < KP4; ++c) acc[c] = f4{0.f, 0.f, 0.f, 0.f};
+    Image<KP> img;
+    if (rb0 < rb1) img.load(Gm, rb0 * TILE, cm.n, tid);
+    for (int64_t rb = rb0; rb < rb1; ++rb) {
+        const int64_t t = rb * cm.ncb + cb;
+        const uint32_t s0 = cm.cslice[t * 17 + sl], s1 = cm.cslice[t * 17 + sl + 1];
+        const int niter = (int)((s1 - s0) >> 6);
+        const int nwave = __builtin_amdgcn_readfirstlane(wave_max_i(niter));
+        const int64_t cbase = cm.coff[t] + s0 + g * 4;                     // this lane's four slots of iteration 0
+        const f4 *sp = reinterpret_cast<const f4 *>(s_cs + cbase);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(cm.ridx + cbase);
+        f4 sq[PD]; uint32_t rq[PD];
+        #pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            sq[d] = f4{0.f, 0.f, 0.f, 0.f}; rq[d] = 0u;
+            if (d < niter) { sq[d] = sp[(int64_t)d * 16]; rq[d] = rp[(int64_t)d * 16]; }
+        }
+        ORIANA_SYNC();
+        img.store(lds, tid);
+        ORIANA_SYNC();
+        if (rb + 1 < rb1) img.load(Gm, (rb + 1) * TILE, cm.n, tid);
+        f4 v[KP4];
+        {
+            const f4 *vrow = lds + (rq[0] & 0xFFu) * ST4;
+            #pragma unroll
+            for (int c = 0; c < KP4; ++c) v[c] = vrow[c];
+        }
+        for (int it = 0; it < nwave; ++it) {
+            const f4 sv = sq[0]; const uint32_t rv = rq[0];
+            #pragma unroll
+            for (int d = 0; d + 1 < PD; ++d) { sq[d] = sq[d + 1]; rq[d] = rq[d + 1]; }
+            sq[PD - 1] = f4{0.f, 0.f, 0.f, 0.f}; rq[PD - 1] = 0u;
+            if (it + PD < niter) { sq[PD - 1] = sp[(int64_t)(it + PD) * 16]; rq[PD - 1] = rp[(int64_t)(it + PD) * 16]; }
+            // (the factor row of the next slot is read while this one is accumulated, as in the row pass)
+#define ORIANA_NCOL_STEP(S, RNEXT)                                                                    \
+            {                                                                                         \
+                f4 vn[KP4];                                                                           \
+                {                                                                                     \
+                    const f4 *nrow = lds + ((RNEXT) & 0xFFu) * ST4;                                   \
+                    _Pragma("unroll") for (int c = 0; c < KP4; ++c) vn[c] = nrow[c];                  \
+                }                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                    \
+                const f2 ss = {(S), (S)};                                                             \
+                _Pragma("unroll") for (int c = 0; c < KP4; ++c) {                                     \
+                    acc[c].xy = __builtin_elementwise_fma(ss, v[c].xy, acc[c].xy);                    \
+                    acc[c].zw = __builtin_elementwise_fma(ss, v[c].zw, acc[c].zw);                    \
+                }                                                                                     \
+                _Pragma("unroll") for (int c = 0; c < KP4; ++c) v[c] = vn[c];                         \
+            }
+            ORIANA_NCOL_STEP(sv.x, rv >> 8)
+            ORIANA_NCOL_STEP(sv.y, rv >> 16)
+            ORIANA_NCOL_STEP(sv.z, rv >> 24)
+            ORIANA_NCOL_STEP(sv.w, rq[0])
+#undef ORIANA_NCOL_STEP
+        }
+    }
+    // through LDS (256 x KP floats: fits the image), then a contiguous flush: a wave's atomics then cover a few
+    // cache lines instead of 64 (scattered, one gene per lane, the flush was 85 of the pass's 109 us at 10,000 x 2,000)
+    const int cl = sl * 16 + g;
+    float *ldsf = reinterpret_cast<float *>(lds);
+    ORIANA_SYNC();
+    #pragma unroll
+    for (int c = 0; c < KP4; ++c) *reinterpret_cast<f4 *>(ldsf + cl * KP + 4 * c) = acc[c];
+    ORIANA_SYNC();
+    if (rb0 < rb1) {
+        const int64_t c0 = cb * TILE, left = cm.m - c0;
+        const int ncols = left < TILE ? (left > 0 ? (int)left : 0) : TILE;
+        flush_block<256>(ldsf, C + c0 * KP, ncols * KP, false, tid);
+    }
+}
+
+}  // namespace narrow
+
 // ------------------------------------------------------------------------------------------
 // dispatch on K:  Kp = 4 * G * T4
 // ------------------------------------------------------------------------------------------
@@ -1461,8 +1756,16 @@ static bool round1_kernels() {
     static const bool r1 = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && e[1] == '1'; }();
     return r1;
 }
+// Kp <= 32: one lane per row (namespace narrow) unless ORIANA_PASS_IMPL says r1 or r2 (A/B measurements)
+static bool narrow_kernels() {
+    static const bool off = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && (e[1] == '1' || e[1] == '2'); }();
+    return !off;
+}
+static bool use_narrow(int G, int T4, int TAIL) { return narrow_kernels() && G == 4 && 4 * T4 + TAIL <= 8; }       // row pass: Kp <= 32
+// (column pass: Kp <= 20 -- at Kp = 32 the two-tile kernel measured 26.0 us against 28.3 at 10,000 x 2,000)
+static bool use_narrow_col(int G, int T4, int TAIL) { return narrow_kernels() && G == 4 && 4 * T4 + TAIL <= 5; }
 static bool use_k100(int G, int T4) { return !round1_kernels() && G == 4 && T4 == 6; }      // row pass, two lanes per row
-static bool use_col2(int G) { return !round1_kernels() && G == 4; }                          // column pass, two tiles per image
+static bool use_col2(int G, int T4, int TAIL) { return !round1_kernels() && G == 4 && !use_narrow_col(G, T4, TAIL); }   // column pass, two tiles per image
 
 template <typename KernelT>
 static int set_lds(KernelT kern, size_t bytes) {
@@ -1482,7 +1785,7 @@ static inline size_t lds_bytes(int G, int T4, int TAIL) {
 template <int G, int T4, int TAIL>
 static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
                            float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s,
-                           const float *FV2 = nullptr) {
+                           const float *FV2 = nullptr, int gene_splits = 1) {
     const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
     if (FV2) {
@@ -1503,13 +1806,22 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
         ORIANA_LAUNCH_CHECK();
         return 0;
     }
+    if constexpr (G == 4 && 4 * T4 + TAIL <= 8) {
+        if (use_narrow(G, T4, TAIL) && var == 0) {
+            constexpr int KP = 4 * G * T4 + G * TAIL;
+            hipLaunchKernelGGL((narrow::k_row_pass_narrow<KP>), dim3((unsigned)cm->nrb, (unsigned)gene_splits), dim3(256),
+                               narrow::Geo<KP>::bytes(), s, *cm, FU, FV, R, s_cs, tile_flag);
+            ORIANA_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (use_k100(G, T4)) {
         constexpr int TL = (G == 4 && T4 == 6) ? TAIL : 0;
         const size_t lb2 = k100::image_bytes(TL);
 #define ORIANA_RP2(V)                                                                                 \
         rc = set_lds(k100::k_row_pass_k100<TL, V>, lb2);                                              \
         if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)cm->nrb), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
+        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)cm->nrb, (unsigned)gene_splits), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
         if (var == 0) { ORIANA_RP2(0); }
         else if (var == 1) { ORIANA_RP2(1); }
         else if (var == 2) { ORIANA_RP2(2); }
@@ -1518,7 +1830,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
         ORIANA_LAUNCH_CHECK();
         return 0;
     }
-    const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block(1024);
+    const dim3 grid((unsigned)(cm->nrb * WaveGeo<G>::SPLIT), (unsigned)gene_splits), block(1024);
     const size_t lb = lds_bytes(G, T4, TAIL);
 #define ORIANA_RP(V)                                                                                  \
     rc = set_lds(k_row_pass<G, T4, TAIL, V>, lb);                                                           \
@@ -1554,7 +1866,31 @@ template <int G, int T4, int TAIL>
 static int launch_col_pass(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C,
                            const int32_t *work, int64_t nwork, float *Cpart, hipStream_t s) {
     constexpr int SPLIT = WaveGeo<G>::SPLIT;
-    if (use_col2(G)) {
+    if constexpr (G == 4 && 4 * T4 + TAIL <= 5) {
+        if (use_narrow_col(G, T4, TAIL) && !Cpart) {
+            // one column tile per work item (oriana_col_block_tiles = 1)
+            constexpr int KP = 4 * G * T4 + G * TAIL;
+            auto kern = narrow::k_col_pass_narrow<KP>;
+            const size_t lbn = narrow::Geo<KP>::bytes();
+            if (work) {
+                if (nwork <= 0) return 0;
+                hipLaunchKernelGGL(kern, dim3((unsigned)nwork), dim3(256), lbn, s, *cm, s_cs, Gm, C, work, (int64_t)0);
+            } else {
+                int64_t nb = (2048 + cm->ncb - 1) / cm->ncb;
+                const int64_t maxb = (cm->nrb + 3) / 4;
+                if (nb > maxb) nb = maxb;
+                if (nb < 1) nb = 1;
+                if (nb > 65535) nb = 65535;
+                const int64_t per = (cm->nrb + nb - 1) / nb;
+                nb = (cm->nrb + per - 1) / per;
+                hipLaunchKernelGGL(kern, dim3((unsigned)cm->ncb, (unsigned)nb), dim3(256), lbn, s, *cm, s_cs, Gm, C,
+                                   (const int32_t *)nullptr, per);
+            }
+            ORIANA_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (use_col2(G, T4, TAIL)) {
         // work items / grid.x index PAIRS of column tiles (oriana_col_block_tiles = 2)
         constexpr int T4c = (G == 4) ? T4 : 1, TLc = (G == 4) ? TAIL : 0;       // (only instantiated for G = 4)
         const size_t lb2 = ColImage<T4c, TLc>::bytes();
@@ -1622,7 +1958,7 @@ extern "C" const char *oriana_version(void) { return "oriana_hip gfx950 0.4"; }
 extern "C" int64_t oriana_col_block_tiles(int64_t K) {
     KCfg c;
     if (!pick_cfg(K, &c)) return 0;
-    return use_col2(c.G) ? 2 : 1;
+    return use_col2(c.G, c.T4, c.TAIL) ? 2 : 1;
 }
 
 static bool counts_ok(const oriana_counts *cm) {
@@ -1650,24 +1986,49 @@ extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const 
 extern "C" int64_t oriana_prep_center_offset(void) { return ((int64_t)sizeof(float) * (8 + 3 * 2 * STATS_MAX_BLOCKS) + 7) / 8 * 8; }
 extern "C" int64_t oriana_prep_scratch_bytes(void) { return oriana_prep_center_offset() + 4096; }
 
-extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
-                                       const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
-                                       int64_t K, float *scratch, void *stream) {
+extern "C" int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                                             const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
+                                             int64_t K, float *scratch, const oriana_clear_list *clr, void *stream) {
     const int64_t Kp = oriana_kpad(K);
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (Kp == 0) return ORIANA_EKRANGE;
-    if (n == 0 && m == 0) return 0;
+    oriana_clear_list cl;
+    memset(&cl, 0, sizeof(cl));
+    int64_t clear_bytes = 0;
+    if (clr) {
+        cl = *clr;
+        for (int e = 0; e < ORIANA_CLEAR_MAX; ++e) {
+            if (cl.bytes[e] < 0 || (cl.bytes[e] & 3) || (cl.bytes[e] > 0 && (!cl.ptr[e] || ((uintptr_t)cl.ptr[e] & 3)))) return ORIANA_EINVAL;
+            clear_bytes += cl.bytes[e];
+        }
+    }
+    if (n == 0 && m == 0 && clear_bytes == 0) return 0;
     if ((n > 0 && (!FU || !logU)) || (m > 0 && (!FV || !logV)) || !scratch) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    auto capped = [](int64_t r) { const int64_t b = (r + 3) / 4; return (int)(b < STATS_MAX_BLOCKS ? b : STATS_MAX_BLOCKS); };
+    // (one work-group per 64 rows, at most STATS_MAX_BLOCKS per side: every group ends with an agent-scope
+    //  release / acquire pair, which on a small matrix costs more than the rows it covers)
+    const int lane_rows = K <= 32 ? 1 : 0;
+    const int64_t rows_per_group = lane_rows ? 256 : 64;
+    auto capped = [&](int64_t r) { const int64_t b = (r + rows_per_group - 1) / rows_per_group; return (int)(b < STATS_MAX_BLOCKS ? b : STATS_MAX_BLOCKS); };
     const int sbu = capped(n), sbv = capped(m);
-    hipLaunchKernelGGL(k_row_stats, dim3((unsigned)(sbu + sbv)), dim3(256), 0, s, scratch, logU, n, logV, maskV, m, (int)K, sbu);
+    if (sbu + sbv > 0)
+        hipLaunchKernelGGL(k_row_stats, dim3((unsigned)(sbu + sbv)), dim3(256), 0, s, scratch, logU, n, logV, maskV, m, (int)K, sbu,
+                           lane_rows);
     const int64_t nbu = (n + 3) / 4, nbv = (m + 3) / 4;
-    if (nbu + nbv > 0x7fffffffLL) return ORIANA_EINVAL;
-    hipLaunchKernelGGL(k_factor_prep_pair, dim3((unsigned)(nbu + nbv)), dim3(256), 0, s, FU, FV, logU, logV, maskV,
-                       row_index_u, row_index_v, n, m, (int)K, (int)Kp, (int)nbu, (const float *)scratch);
+    // zero-fill groups: 16 KB each, at most 4096
+    int64_t ncl = (clear_bytes + 16383) / 16384;
+    if (ncl > 4096) ncl = 4096;
+    if (nbu + nbv + ncl > 0x7fffffffLL) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_factor_prep_pair, dim3((unsigned)(nbu + nbv + ncl)), dim3(256), 0, s, FU, FV, logU, logV, maskV,
+                       row_index_u, row_index_v, n, m, (int)K, (int)Kp, (int)nbu, (int)nbv, (const float *)scratch, cl);
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                                       const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
+                                       int64_t K, float *scratch, void *stream) {
+    return oriana_factor_prep_pair_clear(FU, FV, logU, logV, maskV, row_index_u, row_index_v, n, m, K, scratch, nullptr, stream);
 }
 
 extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz,
@@ -1681,6 +2042,40 @@ extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const f
     if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
 #define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s)
+    ORIANA_FOR_CFG(cfg, CALL);
+#undef CALL
+    return 0;
+}
+
+// Gene-tile split of the plain row pass for short matrices: a row block is one work-group (two for K > 116), so a
+// matrix of 10,000 cells runs the pass on 40 of the 256 CUs; splitting each row block's gene tiles over several groups
+// fills the chip; each group of a row block stores its row sums in its own slab of R, which the consumer adds up
+// (atomics on R cost 1.2 us per split at 10,000 x 20: more than the tile a split saves).
+extern "C" int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t K) {
+    KCfg cfg;
+    if (!cm || !pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 1;
+    const int64_t groups = cm->nrb * ((use_k100(cfg.G, cfg.T4) || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (256 / (16 * (64 / cfg.G))));
+    if (groups >= 256) return 1;
+    // two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20: 77 / 42 / 25 / 24 us
+    // for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
+    static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
+    int64_t sp = forced > 0 ? forced : 512 / groups;
+    if (sp > cm->ncb) sp = cm->ncb;
+    if (sp < 1) sp = 1;
+    const int64_t per = (cm->ncb + sp - 1) / sp;
+    return (cm->ncb + per - 1) / per;
+}
+
+extern "C" int oriana_row_pass_split(const oriana_counts *cm, const float *FU, const float *FV, float *R, float *s_cs,
+                                     int32_t *tile_flag, int64_t K, int64_t gene_splits, void *stream) {
+    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
+    KCfg cfg;
+    if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
+    if (cm->n == 0) return 0;
+    if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
+    if (gene_splits < 1 || gene_splits > 65535 || (cm->ncb > 0 && gene_splits > cm->ncb)) return ORIANA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, nullptr, R, s_cs, nullptr, nullptr, tile_flag, s, nullptr, (int)gene_splits)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -1809,7 +2204,21 @@ extern "C" int oriana_finalize(float *Z, const float *F, const float *R, const f
     if (!Z || !F || !R) return ORIANA_EINVAL;
     const int64_t tot = r * K;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, F, R,
-                       mul, row_index, r, (int)K, (int)Kp, accumulate);
+                       mul, row_index, r, (int)K, (int)Kp, accumulate, 1);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_finalize_slabs(float *Z, const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                                     int64_t r, int64_t K, void *stream) {
+    const int64_t Kp = oriana_kpad(K);
+    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535) return ORIANA_EINVAL;
+    if (Kp == 0) return ORIANA_EKRANGE;
+    if (r == 0) return 0;
+    if (!Z || !F || !R) return ORIANA_EINVAL;
+    const int64_t tot = r * K;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, F, R,
+                       (const float *)nullptr, row_index, r, (int)K, (int)Kp, 1, (int)nslab);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

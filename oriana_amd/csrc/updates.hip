@@ -6,6 +6,7 @@
 // of oriana/utils.py.  All of it is float64 element-wise work plus column sums: HBM-bound,
 // fused so that each parameter matrix is written once and Z is read once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace oriana {
 
@@ -15,15 +16,25 @@ namespace oriana {
 constexpr int GU_ROWS_PER_BLOCK = 512;        // upper bound; rows_per_block() picks fewer for short matrices
 constexpr int GU_MAXCOLS_PER_THREAD = 4;     // K <= 4 * 128
 
-__global__ __launch_bounds__(256) void k_gamma_update(double *__restrict__ a1, double *__restrict__ a2,
+// FIN: the last step of the responsibility pass (oriana_finalize: Z[o] += F[p] * R[p], o = row_index[p]) is folded in:
+// the rows are walked in PACKED order p, Z is completed in place (it stays a full output) and used at once.
+// NT: threads per work-group.  Every group ends with 2K float64 atomics on the SAME 2K addresses, which the memory
+// side serialises (measured: 26 ns per group; a row of a thread is 0.8 us of dependent loads): a short matrix takes few,
+// large groups (1024 threads, 79 of them at 10,000 rows: 17.6 -> ~10 us), a long one many small groups.
+template <bool FIN, int NT>
+__global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, double *__restrict__ a2,
                                                       double *__restrict__ E, float *__restrict__ Elog,
                                                       double *__restrict__ colsum_E, double *__restrict__ colsum_Elog,
                                                       const double *__restrict__ prior1, const double *__restrict__ prior2,
-                                                      const float *__restrict__ Z, const float *__restrict__ zmul,
+                                                      const float *__restrict__ Z_in, const float *__restrict__ zmul,
                                                       const double *__restrict__ rate_vec,
                                                       const double *__restrict__ rate_mat,
-                                                      const float *__restrict__ rmul, int64_t r, int K, int rpb) {
-    __shared__ double red[2][256];
+                                                      const float *__restrict__ rmul, int64_t r, int K, int rpb,
+                                                      float *__restrict__ Zfin, const float *__restrict__ F,
+                                                      const float *__restrict__ Rs, const int32_t *__restrict__ row_index,
+                                                      int Kp, int nslab) {
+    const float *Z = FIN ? Zfin : Z_in;
+    __shared__ double red[2][NT];
     const int KT = blockDim.x, RY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
@@ -33,13 +44,23 @@ __global__ __launch_bounds__(256) void k_gamma_update(double *__restrict__ a1, d
     for (int c = 0; c < GU_MAXCOLS_PER_THREAD; ++c) { sE[c] = 0.0; sL[c] = 0.0; }
 
     for (int64_t row = r0 + ty; row < r1; row += RY) {
+        const int64_t orow = (FIN && row_index) ? (int64_t)row_index[row] : row;
         #pragma unroll
         for (int c = 0; c < GU_MAXCOLS_PER_THREAD; ++c) {
             const int k = tx + c * KT;
             if (k < K) {
-                const int64_t idx = row * K + k;
+                const int64_t idx = orow * K + k;
                 double s1, s2;
-                if (Z) {
+                if (FIN) {
+                    float rr = Rs[row * Kp + k];
+                    for (int sl = 1; sl < nslab; ++sl) rr += Rs[((int64_t)sl * r + row) * Kp + k];
+                    const float zf = fmaf(F[row * Kp + k], rr, Zfin[idx]) + 0.0f;                  // k_finalize (accumulate)
+                    Zfin[idx] = zf;
+                    s1 = clamp_eps(prior1[k] + (double)zf);
+                    s2 = clamp_eps(prior2[k] + rate_vec[k]);
+                    a1[idx] = s1;
+                    a2[idx] = s2;
+                } else if (Z) {
                     double z = (double)Z[idx];
                     if (zmul) z = (double)(zmul[idx] * Z[idx]);          // f32 product, as S_hat * Z_hat_j
                     s1 = clamp_eps(prior1[k] + z);
@@ -61,20 +82,37 @@ __global__ __launch_bounds__(256) void k_gamma_update(double *__restrict__ a1, d
             }
         }
     }
-    // reduce over ty
-    const int flat = ty * KT + tx;
+    // reduce over ty: inside a wave first (KT <= 32: lanes l, l + KT, ... hold the same column), then over the waves
+    // through LDS -- at most NT / 64 terms per column for the thread that issues the atomics
+    const int flat = ty * KT + tx, lane = flat & 63, wv = flat >> 6, NW = NT / 64;
+    const int kw = KT < 64 ? KT : 64;                  // distinct columns inside a wave
     #pragma unroll
     for (int c = 0; c < GU_MAXCOLS_PER_THREAD; ++c) {
+        if (c * KT >= K) break;                        // (uniform: no thread holds a column of this round)
         const int k = tx + c * KT;
+        double vE = sE[c], vL = sL[c];
+        for (int off = kw; off < 64; off <<= 1) { vE += __shfl_xor(vE, off); vL += __shfl_xor(vL, off); }
         __syncthreads();
-        red[0][flat] = sE[c];
-        red[1][flat] = sL[c];
+        if (lane < kw) {
+            // column of this lane inside the round: tx for KT <= 64; for KT = 128 a wave covers half of the columns
+            red[0][wv * kw + lane] = vE;
+            red[1][wv * kw + lane] = vL;
+        }
         __syncthreads();
         if (ty == 0 && k < K) {
             double tE = 0.0, tL = 0.0;
-            for (int y = 0; y < RY; ++y) { tE += red[0][y * KT + tx]; tL += red[1][y * KT + tx]; }
+            if (KT <= 64) {
+                for (int w = 0; w < NW; ++w) { tE += red[0][w * kw + tx]; tL += red[1][w * kw + tx]; }
+            } else {
+                // KT = 128: rows of threads span two waves; wave 2y + (tx >> 6) holds columns (tx & 63) of row y
+                for (int w = (tx >> 6); w < NW; w += 2) { tE += red[0][w * kw + (tx & 63)]; tL += red[1][w * kw + (tx & 63)]; }
+            }
+#ifndef ORIANA_GU_NOATOM
             if (colsum_E) atomicAdd(&colsum_E[k], tE);
             if (colsum_Elog) atomicAdd(&colsum_Elog[k], tL);
+#else
+            if (colsum_E && tE == 1.2345) colsum_E[k] = tL;
+#endif
         }
     }
 }
@@ -122,6 +160,29 @@ __global__ void k_mstep_gamma(double *__restrict__ p1, double *__restrict__ p2, 
     p2[k] = n2;
 }
 
+// both Gamma nodes in one launch (block 0: U side, block 1: V side).  keep_v: the V side's column sums were accumulated
+// in colsum_v (scratch of the sweep) and are copied to keep_v (2K values: sums of E, then of Elog), where the next
+// sweep's cell-side update reads sum_j V_hat.
+__global__ void k_mstep_gamma_pair(double *__restrict__ p1u, double *__restrict__ p2u, const double *__restrict__ cEu,
+                                   const double *__restrict__ cLu, double count_u, double *__restrict__ p1v,
+                                   double *__restrict__ p2v, const double *__restrict__ cEv,
+                                   const double *__restrict__ cLv, double count_v, double *__restrict__ keep_v, int K) {
+    const bool vs = blockIdx.x == 1;
+    double *p1 = vs ? p1v : p1u, *p2 = vs ? p2v : p2u;
+    const double *cE = vs ? cEv : cEu, *cL = vs ? cLv : cLu;
+    const double count = vs ? count_v : count_u;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const double se = cE[k], sl = cL[k];
+        const float mean_log = (float)(sl / count);
+        const double y = log(p2[k]) + (double)mean_log;
+        const double n1 = clamp_eps(inverse_digamma_f64(y));
+        const double n2 = clamp_eps(n1 / (se / count));
+        p1[k] = n1;
+        p2[k] = n2;
+        if (vs && keep_v) { keep_v[k] = se; keep_v[K + k] = sl; }
+    }
+}
+
 enum { OP_DIGAMMA = 0, OP_TRIGAMMA, OP_INVDIGAMMA, OP_SIGMOID, OP_LOGIT };
 template <int OP>
 __global__ void k_map_f64(double *__restrict__ y, const double *__restrict__ x, int64_t len) {
@@ -151,6 +212,8 @@ static int launch_map(double *y, const double *x, int64_t len, void *stream) {
 // per block the gene side (30,000 rows) ran on 59 of the 256 CUs and one rank's share of the cell side
 // (125,000 rows) on 245, a single 4-wave block each: 0.34 ms per call instead of ~0.1.
 static inline int rows_per_block(int64_t r, int ry) {
+    static const int forced = [] { const char *e = getenv("ORIANA_GU_RPB"); return e ? atoi(e) : 0; }();   // tuning runs
+    if (forced > 0) return (forced + ry - 1) / ry * ry;
     int64_t rpb = (r + 2047) / 2048;
     rpb = (rpb + ry - 1) / ry * ry;
     if (rpb < 4 * ry) rpb = 4 * ry;
@@ -158,10 +221,17 @@ static inline int rows_per_block(int64_t r, int ry) {
     return (int)rpb;
 }
 
-static inline void pick_block(int64_t K, dim3 *block) {
+static inline void pick_block(int64_t K, dim3 *block, int threads = 256) {
     int kt = 1;
     while (kt < K && kt < 128) kt <<= 1;
-    *block = dim3(kt, 256 / kt);
+    *block = dim3(kt, threads / kt);
+}
+
+// short matrices: 1024-thread groups, four rows per thread (see k_gamma_update)
+static inline bool gu_large_groups(int64_t r) {
+    static const int forced = [] { const char *e = getenv("ORIANA_GU_THREADS"); return e ? atoi(e) : 0; }();   // tuning runs
+    if (forced) return forced == 1024;
+    return r <= 32768;
 }
 
 }  // namespace oriana
@@ -178,11 +248,44 @@ extern "C" int oriana_gamma_update(double *a1, double *a2, double *E, float *Elo
     if (!a1 || !a2 || !E || !Elog) return ORIANA_EINVAL;
     if (Z && (!prior1 || !prior2 || (!rate_vec && !rate_mat))) return ORIANA_EINVAL;
     dim3 block;
-    pick_block(K, &block);
-    const int rpb = rows_per_block(r, (int)block.y);
+    const bool big = gu_large_groups(r);
+    pick_block(K, &block, big ? 512 : 256);          // (the general form needs more than the 128 VGPRs of a 1024-thread group)
+    const int rpb = big ? 4 * (int)block.y : rows_per_block(r, (int)block.y);
     const int64_t nblk = (r + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_gamma_update, dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog, colsum_E,
-                       colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, rpb);
+    if (big)
+        hipLaunchKernelGGL((k_gamma_update<false, 512>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
+                           colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, rpb,
+                           (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, 0, 1);
+    else
+        hipLaunchKernelGGL((k_gamma_update<false, 256>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
+                           colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, rpb,
+                           (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, 0, 1);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_gamma_update_finalize(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+                                            double *colsum_Elog, const double *prior1, const double *prior2, float *Z,
+                                            const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                                            const double *rate_vec, int64_t r, int64_t K, void *stream) {
+    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535) return ORIANA_EINVAL;
+    const int64_t Kp = oriana_kpad(K);
+    if (K > 128 * GU_MAXCOLS_PER_THREAD || Kp == 0) return ORIANA_EKRANGE;
+    if (r == 0) return 0;
+    if (!a1 || !a2 || !E || !Elog || !Z || !F || !R || !prior1 || !prior2 || !rate_vec) return ORIANA_EINVAL;
+    dim3 block;
+    const bool big = gu_large_groups(r);
+    pick_block(K, &block, big ? 1024 : 256);
+    const int rpb = big ? 4 * (int)block.y : rows_per_block(r, (int)block.y);
+    const int64_t nblk = (r + rpb - 1) / rpb;
+    if (big)
+        hipLaunchKernelGGL((k_gamma_update<true, 1024>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
+                           colsum_E, colsum_Elog, prior1, prior2, (const float *)nullptr, (const float *)nullptr, rate_vec,
+                           (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab);
+    else
+        hipLaunchKernelGGL((k_gamma_update<true, 256>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
+                           colsum_E, colsum_Elog, prior1, prior2, (const float *)nullptr, (const float *)nullptr, rate_vec,
+                           (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
@@ -207,6 +310,18 @@ extern "C" int oriana_mstep_gamma(double *p1, double *p2, const double *colsum_E
     if (!p1 || !p2 || !colsum_E || !colsum_Elog) return ORIANA_EINVAL;
     hipLaunchKernelGGL(k_mstep_gamma, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, (hipStream_t)stream, p1, p2,
                        colsum_E, colsum_Elog, count, (int)K);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_mstep_gamma_pair(double *p1u, double *p2u, const double *colsum_E_u, const double *colsum_Elog_u,
+                                       double count_u, double *p1v, double *p2v, const double *colsum_E_v,
+                                       const double *colsum_Elog_v, double count_v, double *keep_v, int64_t K,
+                                       void *stream) {
+    if (K <= 0 || !(count_u > 0) || !(count_v > 0)) return ORIANA_EINVAL;
+    if (!p1u || !p2u || !colsum_E_u || !colsum_Elog_u || !p1v || !p2v || !colsum_E_v || !colsum_Elog_v) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_mstep_gamma_pair, dim3(2), dim3(K <= 64 ? 64 : 128), 0, (hipStream_t)stream, p1u, p2u, colsum_E_u,
+                       colsum_Elog_u, count_u, p1v, p2v, colsum_E_v, colsum_Elog_v, count_v, keep_v, (int)K);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -477,7 +477,7 @@ class ZWorkspace:
         f32 = dict(dtype=torch.float32, device=dev)
         self.FU = torch.zeros(max(ct.n, 1), self.Kp, **f32)
         self.FV = torch.zeros(max(ct.m, 1), self.Kp, **f32)
-        self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32)
+        self.R = None          # allocated below: (n, Kp), or one slab per gene split of the row pass
         self.C = torch.zeros(max(ct.m, 1), self.Kp, **f32)
         # per-sweep scalars s_ij in column-side slots: padding slots must stay 0, hence zeros()
         self.s_cs = torch.zeros(max(ct.cslots, 1), **f32)
@@ -489,6 +489,13 @@ class ZWorkspace:
         self.center_ptr = ptr(self.stats) + int(_lib.load().oriana_prep_center_offset())    # {sum, count} of E[log U] per factor (log sums)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
+        self._clear_cache = {}
+        # gene-tile split of the plain row pass (short matrices; 1 = one work-group per row block)
+        self.row_gene_splits = 1
+        if ct.ms > 0 and ct.n > 0 and os.environ.get('ORIANA_ROW_SPLIT', 'auto') != 'off':
+            self.row_gene_splits = max(1, int(_lib.load().oriana_row_pass_gene_splits(ct.sparse_struct, int(K))))
+        gs = self.row_gene_splits
+        self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32) if gs == 1 else torch.zeros(gs, ct.n, self.Kp, **f32)
         if ct.dense is not None:
             if not dense_supported(K):
                 raise _lib.OrianaHipError('K=%d has no dense-gene kernels (oriana_dense_supported): pack without dense_density' % K)
@@ -517,11 +524,19 @@ class KernelTimer:
     """HIP-event timing of individual launches on the stream they are launched on (torch's
     current stream, which is the stream handed to the C ABI)."""
 
-    def __init__(self):
+    def __init__(self, prealloc=0):
+        """`prealloc`: event pairs created up front (creating an event costs microseconds of host time: on a small
+        matrix that is comparable with the launches being timed)."""
         self.records = []
+        self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(int(prealloc))]
 
     def span(self, name):
         return _Span(self, name)
+
+    def _events(self):
+        if self._pool:
+            return self._pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def summary(self):
         """{name: (count, mean_ms)} -- call after torch.cuda.synchronize()."""
@@ -540,8 +555,7 @@ class _Span:
         self.timer, self.name = timer, name
 
     def __enter__(self):
-        self.a = torch.cuda.Event(enable_timing=True)
-        self.b = torch.cuda.Event(enable_timing=True)
+        self.a, self.b = self.timer._events()
         self.a.record()
 
     def __exit__(self, *exc):
@@ -581,10 +595,37 @@ def set_deterministic(flag=True):
     DETERMINISTIC = bool(flag)
 
 
-def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None):
+def _clear_list(ws, tensors):
+    """struct oriana_clear_list over `tensors` (cached per set of buffers: a sweep hands in the same ones every time)."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    key = tuple((t.data_ptr(), t.numel() * t.element_size()) for t in tensors)
+    hit = ws._clear_cache.get(key)
+    if hit is None:
+        if len(key) > 8:
+            raise ValueError('at most 8 buffers can ride on the factor preparation')
+        cl = _lib.OrianaClearList()
+        for i, (p, b) in enumerate(key):
+            cl.ptr[i] = p
+            cl.bytes[i] = b
+        if len(ws._clear_cache) > 16:
+            ws._clear_cache.clear()
+        hit = ws._clear_cache[key] = cl
+    return hit
+
+
+def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None, clear=None):
     """FU, FV of the workspace from E[log U], E[log V] (+ S_tilde), validity test centred on the typical shifts of
-    the two sides (oriana_factor_prep_pair): the sweeps drift along U c, V / c and only the sums matter."""
+    the two sides (oriana_factor_prep_pair): the sweeps drift along U c, V / c and only the sums matter.  `clear`: up to 8
+    contiguous tensors zero-filled by the same launch (the outputs and scratch the passes accumulate into)."""
     ct = ws.ct
+    if clear:
+        for t in clear:
+            if t is not None and not t.is_contiguous():
+                raise ValueError('buffers on the clear list must be contiguous')
+        cl = _clear_list(ws, clear)
+        call('oriana_factor_prep_pair_clear', ptr(ws.FU), ptr(ws.FV), ptr(log_U_hat), ptr(log_V_hat), ptr(mask_v),
+             ptr(ct.row_perm), ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), ctypes.byref(cl), stream_ptr())
+        return
     call('oriana_factor_prep_pair', ptr(ws.FU), ptr(ws.FV), ptr(log_U_hat), ptr(log_V_hat), ptr(mask_v), ptr(ct.row_perm),
          ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), stream_ptr())
 
@@ -621,12 +662,15 @@ def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K):
     return rc == 0
 
 
-def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
+def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_rows=True, finalize_cols=True, clear=()):
     """GaP.compute_Z_q_expectations (reference gap.py:67-80) on the resident tiles: outputs first,
     zero-filled by the callee, returns None.  `phase`: 'rows' stops once Z_hat_i is final (factor
     preparation, row pass, slow path, row-side finalize), 'cols' does the rest (column pass, gene-side finalize):
     the cell-side Gamma update only needs Z_hat_i, so a sharded sweep runs it between the two and has every
-    partial of its single exchange ready when the column pass ends."""
+    partial of its single exchange ready when the column pass ends.
+    finalize_rows / finalize_cols = False: the caller completes Z_hat_i / Z_hat_j itself (the pCMF sweep folds
+    Z += F * R into its Gamma updates, oriana_gamma_update_finalize); until then they hold the slow path's additions
+    only.  `clear`: further buffers (at most 3) zero-filled by the factor preparation's launch."""
     ct, K = ws.ct, ws.K
     st = stream_ptr()
     dn = ct.dense
@@ -636,14 +680,18 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
     if phase in ('all', 'rows'):
         _check_f32(Z_hat_i, (ct.n, K)); _check_f32(Z_hat_j, (ct.m, K))
         _check_f32(log_U_hat, (ct.n, K)); _check_f32(log_V_hat, (ct.m, K))
-        factor_prep_pair(ws, log_U_hat, log_V_hat)
-        Z_hat_i.zero_(); Z_hat_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
+        # short matrices: the gene tiles of a row block are split over several work-groups, which add into R
+        gs = ws.row_gene_splits
+        zero_R = ws.R if ct.ms == 0 else None              # (no sliced part: the dense row pass adds into it)
+        factor_prep_pair(ws, log_U_hat, log_V_hat, clear=(Z_hat_i, Z_hat_j, ws.C, ws.tile_flag, zero_R) + tuple(clear))
         if ct.ms > 0:
             with _span(ws, 'row_pass'):
-                call('oriana_row_pass', ct.sparse_struct, ptr(ws.FU), FVs, None, ptr(ws.R), ptr(ws.s_cs), None, None,
-                     ptr(ws.tile_flag), K, st)
-        else:
-            ws.R.zero_()
+                if gs > 1:
+                    call('oriana_row_pass_split', ct.sparse_struct, ptr(ws.FU), FVs, ptr(ws.R), ptr(ws.s_cs),
+                         ptr(ws.tile_flag), K, gs, st)
+                else:
+                    call('oriana_row_pass', ct.sparse_struct, ptr(ws.FU), FVs, None, ptr(ws.R), ptr(ws.s_cs), None, None,
+                         ptr(ws.tile_flag), K, st)
         if dn is not None:
             with _span(ws, 'dense_images'):
                 call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
@@ -657,7 +705,8 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
             if dn is not None:
                 call('oriana_dense_fixup', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
                      ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_hat_i), ptr(Z_hat_j), K, st)
-        call('oriana_finalize', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), ct.n, K, 1, st)
+        if finalize_rows:
+            call('oriana_finalize_slabs', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), gs, ptr(ct.row_perm), ct.n, K, st)
     if phase in ('all', 'cols'):
         if ct.ms > 0:
             with _span(ws, 'col_pass'):
@@ -668,7 +717,8 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all'):
             with _span(ws, 'dense_col'):
                 call('oriana_dense_col_pass', dn.c_struct, ptr(ws.dn_imgU), ptr(ws.dn_S), ptr(ws.C), K,
                      ws.dn_cell_splits, st)
-        call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
+        if finalize_cols:
+            call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
 
 
 def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
@@ -709,10 +759,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
     sw_cs = ws.sw_cs if w_nz is not None else None
     if phase in ('all', 'rows'):
-        factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=S_tilde)
-        Z_i.zero_(); Z_j.zero_(); ws.C.zero_(); ws.tile_flag.zero_()
-        if Z_log is not None:
-            Z_log.zero_()
+        factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=S_tilde, clear=(Z_i, Z_j, ws.C, ws.tile_flag, Z_log))
         # sparse models: the S_hat-weighted row sums (sparse_gap.py:95).  Where two factor images fit in LDS (Kp <= 64)
         # they come out of the row pass itself (dot product against FV, accumulation against FV * S_hat); otherwise the
         # pass leaves s in row-side slots and a second row product follows.

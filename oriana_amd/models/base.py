@@ -147,6 +147,10 @@ class FactorModel:
         self._Zj = self._xch.f32['Zj']
         self._sumU = torch.zeros(2, K, **f64)        # [sum_i U_hat, sum_i log_U_hat]
         self._sumV = torch.zeros(2, K, **f64)
+        # the gene side's column sums while a sweep accumulates them (cleared with the other scratch of the sweep by the
+        # factor preparation's launch; the M-step copies them to _sumV, which the next cell-side update reads)
+        self._accV = torch.zeros(2, K, **f64)
+        self._v_sums_in_acc = False
         self._ws = engine.ZWorkspace(self.counts, K, need_sw=False, need_srow=False)     # (s_rs: allocated on first use)
         self._init_extra()
         self.U = _Buffer(lambda: self._U_hat)
@@ -287,18 +291,35 @@ class FactorModel:
         """Counts the writes to the expectations a product kept across sweeps depends on (V_hat, S_hat, D_hat)."""
         self._ver += 1
 
-    def _gamma_side(self, side, Z, zmul=None, rate_vec=None, rate_mat=None, rmul=None, update=True):
-        """One side of update_variational_parameters + Gamma.mean / meanlog (oriana_gamma_update)."""
+    def _gamma_side(self, side, Z, zmul=None, rate_vec=None, rate_mat=None, rmul=None, update=True, sums_arg=None, zero=True):
+        """One side of update_variational_parameters + Gamma.mean / meanlog (oriana_gamma_update).  `sums_arg`: where the
+        column sums go (default: _sumU / _sumV); zero=False: they are zero already."""
         if side == 'v':
             self._touch()
         if side == 'u':
             s1, s2, E, Elog, sums, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self._sumU, self.alpha1, self.alpha2, self.n
         else:
             s1, s2, E, Elog, sums, p1, p2, r = self.b1, self.b2, self._V_hat, self._log_V_hat, self._sumV, self.beta1, self.beta2, self.m
-        sums.zero_()
+        if sums_arg is not None:
+            sums = sums_arg
+        if zero:
+            sums.zero_()
         call('oriana_gamma_update', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
              ptr(p1.tensor), ptr(p2.tensor), ptr(Z) if update else None, ptr(zmul), ptr(rate_vec), ptr(rate_mat),
              ptr(rmul), r, self.k, stream_ptr())
+
+    def _gamma_side_finalize(self, side, Z, F, R, row_index, rate_vec, sums, nslab=1):
+        """pCMF: Z += F * R (the last step of the responsibility pass, packed rows scattered through `row_index`) and the
+        Gamma update of that side in one launch (oriana_gamma_update_finalize).  `sums` (2, K) must be zero on entry."""
+        if side == 'v':
+            self._touch()
+        if side == 'u':
+            s1, s2, E, Elog, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self.alpha1, self.alpha2, self.n
+        else:
+            s1, s2, E, Elog, p1, p2, r = self.b1, self.b2, self._V_hat, self._log_V_hat, self.beta1, self.beta2, self.m
+        call('oriana_gamma_update_finalize', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
+             ptr(p1.tensor), ptr(p2.tensor), ptr(Z), ptr(F), ptr(R), int(nslab), ptr(row_index), ptr(rate_vec), r, self.k,
+             stream_ptr())
 
     def _mstep_side(self, side):
         if side == 'u':
@@ -313,11 +334,16 @@ class FactorModel:
         self._gamma_side('u', None, update=False)
         odist.all_reduce_sum(self._sumU, self.pg)
         self._gamma_side('v', None, update=False)
+        self._v_sums_in_acc = False
 
     def update_prior_hyper_parameters(self):
-        """gap.py:117-129."""
-        self._mstep_side('u')
-        self._mstep_side('v')
+        """gap.py:117-129: both Gamma nodes in one launch."""
+        acc = self._v_sums_in_acc
+        sv = self._accV if acc else self._sumV
+        call('oriana_mstep_gamma_pair', ptr(self.alpha1.tensor), ptr(self.alpha2.tensor), ptr(self._sumU[0]),
+             ptr(self._sumU[1]), float(self.n_total), ptr(self.beta1.tensor), ptr(self.beta2.tensor), ptr(sv[0]), ptr(sv[1]),
+             float(self.m), ptr(self._sumV) if acc else None, self.k, stream_ptr())
+        self._v_sums_in_acc = False
 
     def update_variational_parameters(self):
         raise NotImplementedError

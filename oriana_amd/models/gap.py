@@ -22,11 +22,24 @@ class GaP(FactorModel):
         # both Z sums use the PRE-update E[log U], E[log V] (one joint pass, gap.py:89-94); the cell side only
         # needs Z_i, so its update runs between the row pass and the column pass and every partial of the
         # sweep's single exchange exists when the column pass ends
-        engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows')
+        # Launch count matters on a small matrix (configs[1]: a sweep is ~10 launches of a few microseconds of work each):
+        # the zero-fills ride on the factor preparation, Z += F * R on the Gamma updates, both M-steps share a launch.
+        ws, ct = self._ws, self.counts
+        if self._v_sums_in_acc:                # an E-step without the M-step before it: sum_j V_hat is still in scratch
+            self._sumV.copy_(self._accV)
+            self._v_sums_in_acc = False
+        fold_cols = self.world == 1            # (under row sharding Z_j is completed per rank, then exchanged)
+        engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows', finalize_rows=False,
+                      clear=(self._sumU, self._accV))
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
-        self._gamma_side('u', self._Zi, rate_vec=self._sumV[0])
+        self._gamma_side_finalize('u', self._Zi, ws.FU, ws.R, ct.row_perm, self._sumV[0], self._sumU, nslab=ws.row_gene_splits)
         self._exchange_start()                  # sum_i U_hat | sum_i log U_hat (float64): reduced under the column pass
-        engine.zq_gap(self._ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='cols')
+        engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='cols', finalize_cols=not fold_cols)
         self._exchange()                        # Z_j (float32, 12 MB at C4) + wait for the sums
         # V_q: b1 = beta1 + Z_j ; b2 = beta2 + sum_i U_hat (NEW U_hat)                   gap.py:105-110
-        self._gamma_side('v', self._Zj, rate_vec=self._sumU[0])
+        # (its column sums go to scratch: _sumV still holds sum_j V_hat of the sweep's start, which the M-step replaces)
+        if fold_cols:
+            self._gamma_side_finalize('v', self._Zj, ws.FV, ws.C, ct.col_perm, self._sumU[0], self._accV)
+        else:
+            self._gamma_side('v', self._Zj, rate_vec=self._sumU[0], sums_arg=self._accV, zero=False)
+        self._v_sums_in_acc = True

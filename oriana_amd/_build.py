@@ -10,8 +10,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'dense_mfma.hip', 'dense_f32.hip', 'dense_pass.hip', 'metrics.hip', 'stateless.hip']
+SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'dense_mfma.hip', 'dense_f32.hip', 'dense_pass.hip', 'dense_zi.hip', 'metrics.hip', 'stateless.hip']
 LIB = os.path.join(CSRC, 'liboriana_hip.so')
+# dense_zi.hip: the loop body of k_zi_row<6, 1> is ONE fully unrolled basic block of ~2700 instructions (a hand-placed
+# slot plan of matrix and vector instructions); it exceeds the default size limit of `#pragma unroll`
+EXTRA_FLAGS = {'dense_zi.hip': ['-mllvm', '-pragma-unroll-threshold=65536']}
 ARCH = 'gfx950'
 
 
@@ -27,7 +30,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps += [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'oriana_hip.h')]
+    deps += [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')] + [os.path.join(HERE, '..', 'include', 'oriana_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -43,7 +46,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(CSRC, s.replace('.hip', '.o'))
         cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall',
-               '-Wno-unused-function', '-c', src, '-o', obj]
+               '-Wno-unused-function'] + EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -1052,14 +1052,27 @@ static int launch_dt(double *out, const float *D, const double *W, int64_t n, in
     return 0;
 }
 
+// 64 < K <= 100 (gene count a multiple of 4): csrc/dense_zi.hip
+namespace dn {
+bool zi_supported(int64_t m, int64_t K);
+int64_t zi_sweep_image_floats(int64_t m);
+int64_t zi_dt_image_floats(int64_t n);
+int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, const uint32_t *nzmask, double *colsum,
+             const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m, int K, hipStream_t st);
+int zi_dt(double *out, const float *D, const double *W, float *scratch, int64_t n, int64_t m, int K, hipStream_t st);
+}  // namespace dn
+
 }  // namespace oriana
 
 using namespace oriana;
 
 extern "C" int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K) {
     if (m < 0 || K < 0) return 0;
-    // logit(pi_d) + the two operand images of the bf16 path at their largest (K <= 64: 4 k chunks, 2 n tiles)
-    return (m + 63) / 64 * 64 + b16_img_floats(m, 4 * 3 * 64) + b16_img_floats(m, 2 * 2 * 3 * 64);
+    // logit(pi_d) + the two operand images of the bf16 path at their largest (K <= 64: 4 k chunks, 2 n tiles; or the
+    // images of csrc/dense_zi.hip for 64 < K <= 100)
+    const int64_t a = b16_img_floats(m, 4 * 3 * 64) + b16_img_floats(m, 2 * 2 * 3 * 64);
+    const int64_t b = (K > 64 && K <= 100) ? dn::zi_sweep_image_floats(m) : 0;
+    return (m + 63) / 64 * 64 + (a > b ? a : b);
 }
 
 extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d64,
@@ -1083,6 +1096,8 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
             case 3: rc = launch_sweep_b16<2, 3>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
             default: rc = launch_sweep_b16<2, 4>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
         }
+    } else if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K)) {
+        rc = dn::zi_sweep(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, scratch + (m + 63) / 64 * 64, n, m, (int)K, st);
     } else {
         switch ((int)((K + 31) / 32)) {
             case 1: rc = launch_sweep<1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
@@ -1098,7 +1113,9 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
 
 extern "C" int64_t oriana_dense_t_scratch_floats(int64_t n, int64_t K) {
     if (n < 0 || K < 0) return 0;
-    return ((n + 15) / 16 + 4) * (int64_t)(2 * 3 * 64) * 4;       // operand images of W at their largest (K <= 64)
+    const int64_t a = ((n + 15) / 16 + 4) * (int64_t)(2 * 3 * 64) * 4;       // operand images of W at their largest (K <= 64)
+    const int64_t b = (K > 64 && K <= 100) ? dn::zi_dt_image_floats(n) : 0;   // csrc/dense_zi.hip
+    return a > b ? a : b;
 }
 
 extern "C" int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W, float *scratch, int arithmetic,
@@ -1114,6 +1131,8 @@ extern "C" int oriana_dense_t_times_factor_f32(double *out, const float *D, cons
         if (!scratch || ((uintptr_t)scratch & 15) != 0) return ORIANA_EINVAL;
         if (K <= 32) rc = launch_dt_b16<1>(out, D, W, scratch, n, m, (int)K, st);
         else rc = launch_dt_b16<2>(out, D, W, scratch, n, m, (int)K, st);
+    } else if (arithmetic == ORIANA_MATRIX_BF16X3 && scratch && ((uintptr_t)scratch & 15) == 0 && dn::zi_supported(m, K)) {
+        rc = dn::zi_dt(out, D, W, scratch, n, m, (int)K, st);
     } else {
         switch ((int)((K + 31) / 32)) {
             case 1: rc = launch_dt<1, 4>(out, D, W, n, m, (int)K, st); break;

@@ -536,7 +536,11 @@ def test_dropout_update_fused_matches_unfused(n, m, K):
 # ---- the dense work of a ZI sweep on the float32 matrix cores (csrc/dense_f32.hip) -------------------------------
 
 F32_SHAPES = [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 1024, 100), (129, 2050, 33),
-              (2000, 70, 64), (260, 300, 97), (70, 90, 128), (5000, 3001, 50), (4100, 600, 50)]
+              (2000, 70, 64), (260, 300, 97), (70, 90, 128), (5000, 3001, 50), (4100, 600, 50),
+              # 64 < K <= 100 with a gene count that is a multiple of 4: csrc/dense_zi.hip (every (KC, TAIL) pair, partial
+              # cell and gene tiles, fewer cells than a tile, several gene ranges / cell ranges per work-group column)
+              (33, 36, 65), (3000, 2080, 84), (700, 5000, 96), (257, 132, 100), (9000, 420, 80), (31, 4, 100),
+              (513, 1022, 100)]
 
 
 @pytest.mark.gpu

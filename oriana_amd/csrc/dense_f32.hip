@@ -1052,9 +1052,10 @@ static int launch_dt(double *out, const float *D, const double *W, int64_t n, in
     return 0;
 }
 
-// 64 < K <= 100 (gene count a multiple of 4): csrc/dense_zi.hip
+// 32 < K <= 100 except Kp = 64 (gene count a multiple of 4): csrc/dense_zi.hip
 namespace dn {
 bool zi_supported(int64_t m, int64_t K);
+bool zi_dt_supported(int64_t m, int64_t K);
 int64_t zi_sweep_image_floats(int64_t m);
 int64_t zi_dt_image_floats(int64_t n);
 int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, const uint32_t *nzmask, double *colsum,
@@ -1071,7 +1072,7 @@ extern "C" int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K) {
     // logit(pi_d) + the two operand images of the bf16 path at their largest (K <= 64: 4 k chunks, 2 n tiles; or the
     // images of csrc/dense_zi.hip for 64 < K <= 100)
     const int64_t a = b16_img_floats(m, 4 * 3 * 64) + b16_img_floats(m, 2 * 2 * 3 * 64);
-    const int64_t b = (K > 64 && K <= 100) ? dn::zi_sweep_image_floats(m) : 0;
+    const int64_t b = (K > 32 && K <= 100) ? dn::zi_sweep_image_floats(m) : 0;
     return (m + 63) / 64 * 64 + (a > b ? a : b);
 }
 
@@ -1088,7 +1089,9 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
     hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, pi_d64, m);
     const float *pi_d = scratch;
     int rc;
-    if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K)) {
+        rc = dn::zi_sweep(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, scratch + (m + 63) / 64 * 64, n, m, (int)K, st);
+    } else if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
         float *img = scratch + (m + 63) / 64 * 64;
         switch ((int)((K + 15) / 16)) {
             case 1: rc = launch_sweep_b16<1, 1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
@@ -1096,8 +1099,6 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
             case 3: rc = launch_sweep_b16<2, 3>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
             default: rc = launch_sweep_b16<2, 4>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
         }
-    } else if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K)) {
-        rc = dn::zi_sweep(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, scratch + (m + 63) / 64 * 64, n, m, (int)K, st);
     } else {
         switch ((int)((K + 31) / 32)) {
             case 1: rc = launch_sweep<1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, n, m, (int)K, st); break;
@@ -1114,7 +1115,7 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
 extern "C" int64_t oriana_dense_t_scratch_floats(int64_t n, int64_t K) {
     if (n < 0 || K < 0) return 0;
     const int64_t a = ((n + 15) / 16 + 4) * (int64_t)(2 * 3 * 64) * 4;       // operand images of W at their largest (K <= 64)
-    const int64_t b = (K > 64 && K <= 100) ? dn::zi_dt_image_floats(n) : 0;   // csrc/dense_zi.hip
+    const int64_t b = (K > 32 && K <= 100) ? dn::zi_dt_image_floats(n) : 0;   // csrc/dense_zi.hip
     return a > b ? a : b;
 }
 
@@ -1127,12 +1128,12 @@ extern "C" int oriana_dense_t_times_factor_f32(double *out, const float *D, cons
     if (arithmetic != ORIANA_MATRIX_F32 && arithmetic != ORIANA_MATRIX_BF16X3) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && scratch && ((uintptr_t)scratch & 15) == 0 && dn::zi_dt_supported(m, K)) {
+        rc = dn::zi_dt(out, D, W, scratch, n, m, (int)K, st);
+    } else if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
         if (!scratch || ((uintptr_t)scratch & 15) != 0) return ORIANA_EINVAL;
         if (K <= 32) rc = launch_dt_b16<1>(out, D, W, scratch, n, m, (int)K, st);
         else rc = launch_dt_b16<2>(out, D, W, scratch, n, m, (int)K, st);
-    } else if (arithmetic == ORIANA_MATRIX_BF16X3 && scratch && ((uintptr_t)scratch & 15) == 0 && dn::zi_supported(m, K)) {
-        rc = dn::zi_dt(out, D, W, scratch, n, m, (int)K, st);
     } else {
         switch ((int)((K + 31) / 32)) {
             case 1: rc = launch_dt<1, 4>(out, D, W, n, m, (int)K, st); break;

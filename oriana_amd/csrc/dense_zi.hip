@@ -1,4 +1,4 @@
-// dense_zi.hip -- the two dense contractions of a ZI sweep for 64 < K <= 100 on the bf16 matrix cores, float32-equivalent
+// dense_zi.hip -- the two dense contractions of a ZI sweep for 32 < K <= 100 on the bf16 matrix cores, float32-equivalent
 // arithmetic (exact three-way bf16 splits, six cross products, float32 accumulation, no chain beyond 256 terms; the
 // tail factors Kp - 16 KC on the float32 matrix instructions): the kernels of dense_pass.hip with the sigmoid in the
 // place of s = x / den.
@@ -9,9 +9,10 @@
 //              dn::k_dn_row (S(t) beside the matrix instructions of Lambda(t + 1), then the product of tile t).
 //   k_zi_col   out[gene, k] += sum_i D_hat[i, gene] W[i, k]  (zigap.py:124): dn::k_dn_col reading D_hat row-major.
 //
-// dense_f32.hip keeps K <= 64 (its kernels are faster there: 3.9 against 4.4 ms at 100k x 20k, K = 50) and the float32
-// matrix instruction for K > 100 or a gene count that is not a multiple of 4 (16-byte row pieces).
+// Serves 33 <= K <= 100 except Kp = 64 (zi_cfg below: measured assignment); dense_f32.hip keeps K <= 32, Kp = 64, and the
+// float32 matrix instruction for K > 100 or a gene count that is not a multiple of 4 (16-byte row pieces).
 #include "dense_tiles.h"
+#include <stdlib.h>
 
 namespace oriana {
 namespace dn {
@@ -570,19 +571,35 @@ static int64_t zi_pick_splits(int64_t blocks, int64_t max_splits) {
         else if (KC_ == 5 && TL_ == 1) { CALL(5, 1); }                        \
         else if (KC_ == 5 && TL_ == 0) { CALL(5, 0); }                        \
         else if (KC_ == 4 && TL_ == 1) { CALL(4, 1); }                        \
+        else if (KC_ == 3 && TL_ == 1) { CALL(3, 1); }                        \
+        else if (KC_ == 3 && TL_ == 0) { CALL(3, 0); }                        \
         else return ORIANA_EKRANGE;                                           \
     } while (0)
 
-static bool zi_cfg(int64_t K, int *kc, int *tl) {
-    const int64_t Kp = oriana_kpad(K);
-    if (K <= 64 || Kp == 0 || Kp > 100 || (Kp % 16 != 0 && Kp % 16 != 4)) return false;
-    *kc = (int)(Kp / 16); *tl = (Kp % 16 == 4) ? 1 : 0;
-    return *kc == 5 || *kc == 6 || (*kc == 4 && *tl == 1);                // Kp = 68, 80, 84, 96, 100
+// Smallest K served here: 33.  Measured at 100k x 20k against dense_f32.hip's bf16 kernels (tools/perf_zi_dense.py): D update
+// 3.45 against 4.11 ms at K = 48, 3.82 against 4.00 ms at K = 50; D^T U 1.82 against 2.00 ms at K = 48 but 2.06 against
+// 1.98 ms at K = 50 (the tail factors' 4 x 4 x 1 instructions): below 65 the transposed product comes here only when Kp has
+// no tail.  ORIANA_ZI_DN_MINK raises the limit for A/B measurements (65: round 2's assignment).
+static int64_t zi_min_k() {
+    static const int64_t v = [] { const char *e = getenv("ORIANA_ZI_DN_MINK"); const long x = e ? atol(e) : 33; return (int64_t)(x < 33 ? 33 : x); }();
+    return v;
 }
 
-bool zi_supported(int64_t m, int64_t K) {
+static bool zi_cfg(int64_t K, int *kc, int *tl) {
+    const int64_t Kp = oriana_kpad(K);
+    if (K < zi_min_k() || Kp == 0 || Kp > 100 || (Kp % 16 != 0 && Kp % 16 != 4)) return false;
+    *kc = (int)(Kp / 16); *tl = (Kp % 16 == 4) ? 1 : 0;
+    return *kc >= 3 && *kc <= 6 && !(*kc == 4 && *tl == 0);               // Kp = 48 .. 100 (Kp = 64: the image has no padding)
+}
+
+bool zi_supported(int64_t m, int64_t K) {                                  // the D update
     int kc, tl;
     return (m % 4) == 0 && zi_cfg(K, &kc, &tl);
+}
+
+bool zi_dt_supported(int64_t m, int64_t K) {                               // D_hat^T W
+    int kc, tl;
+    return (m % 4) == 0 && zi_cfg(K, &kc, &tl) && (K > 64 || tl == 0);
 }
 
 // floats of scratch for the gene-side images of m genes / the cell-side images of n cells (largest configuration)
@@ -618,7 +635,7 @@ int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, 
 
 int zi_dt(double *out, const float *D, const double *W, float *scratch, int64_t n, int64_t m, int K, hipStream_t st) {
     int kc, tl;
-    if (!zi_cfg(K, &kc, &tl) || (m % 4) != 0) return ORIANA_EKRANGE;
+    if (!zi_dt_supported(m, K) || !zi_cfg(K, &kc, &tl)) return ORIANA_EKRANGE;
     const int ngt = (int)((m + 31) / 32);
     const int64_t nct = (n + 31) / 32;
     const int64_t groups = (ngt + NW - 1) / NW;

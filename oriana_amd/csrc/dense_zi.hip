@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     using C = Cfg<KC, TAIL>;
     constexpr int NT = C::NT;
     constexpr int MP = C::PV_RAW;                                          // first mask piece inside an image buffer
+    constexpr bool DMA_TOP = KC <= 3;
     extern __shared__ u4v ldsq[];
     u4v *img = ldsq;                                                      // [3][PV]
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -234,9 +235,12 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
         const u4v *im0 = img + buf * C::PV;                                // tile gt: second product, masks, logits
         const int64_t j0 = (int64_t)gt * 32;
         if (gt > gt0) colsum_flush(gt - 1, par ^ 1);
-        // the image, masks and logits of tile gt + 2 go out now, into the buffer tile gt - 1 left at the last barrier
-        zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, mrow_l, m,
-                              w, lane);
+        // The image, masks and logits of tile gt + 2 go out into the buffer tile gt - 1 has left: in the middle of the
+        // matrix work for the long loops (item 16 below; measured at 100k x 20k: 5.10 against 5.26 ms at K = 100, 4.38 / 4.46
+        // at K = 80), here at the top for KC <= 3 (3.45 against 3.78 ms at K = 48)
+        if (DMA_TOP)
+            zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, mrow_l, m,
+                                  w, lane);
         u4v A0[2], A1, A2;
         A2 = im1[2 * 64 + lane]; A0[0] = im1[0 * 64 + lane]; A1 = im1[1 * 64 + lane];
         f16v l0 = dn;                                                      // Lambda^T of tile gt -> p
@@ -296,6 +300,9 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const f4v *>(Tr + 8 * q * TS);
+                    if (!DMA_TOP)
+                        zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0,
+                                              mrow_l, m, w, lane);
                 } else if (it == 17) {
                     // D_hat rows out
                     const uint32_t vo = (j0 + gq < m) ? dvoff : 0x80000000u;

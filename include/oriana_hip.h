@@ -428,7 +428,8 @@ int oriana_dense_times_factor(double *out, const float *D, const double *W, int6
  * V_next).  arithmetic: how the float32 products are evaluated --
  *   ORIANA_MATRIX_F32     v_mfma_f32_32x32x2_f32 (a chain of single-rounding float32 FMAs);
  *   ORIANA_MATRIX_BF16X3  each float32 operand split into three bf16, six cross products on the bf16 matrix cores,
- *                         float32 accumulation (K <= 64; larger K silently take the float32 instruction): the same
+ *                         float32 accumulation (K <= 100 when the gene count is a multiple of 4, K <= 64 otherwise;
+ *                         larger K silently take the float32 instruction; csrc/dense_f32.hip, csrc/dense_zi.hip): the same
  *                         error as the float32 chain on sums of <= 512 terms (which is all the kernel forms before it
  *                         leaves the matrix core), 2.7 x its rate. */
 #define ORIANA_MATRIX_F32     0

@@ -58,7 +58,7 @@ class _ZIMixin:
         self._lg_scratch = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, self.k)), dtype=torch.float32, device=dev)
         self._dt_scratch = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, self.k)), dtype=torch.float32, device=dev)
         # how the float32 products are evaluated (include/oriana_hip.h): 1 = three-way bf16 splits on the bf16 matrix
-        # cores (K <= 64), 0 = the float32 matrix instruction
+        # cores (K <= 100; K <= 64 when the gene count is not a multiple of 4), 0 = the float32 matrix instruction
         self._matrix_arith = {'f32': 0, 'bf16x3': 1}[os.environ.get('ORIANA_ZI_MATRIX', 'bf16x3')]
 
     @property

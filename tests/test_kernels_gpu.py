@@ -548,7 +548,7 @@ F32_SHAPES = [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 102
 @pytest.mark.parametrize('arithmetic', [0, 1], ids=['f32', 'bf16x3'])
 def test_dense_t_times_factor_f32(n, m, K, arithmetic):
     """D_hat^T U_hat (zigap.py:124) with float32 products (the float32 matrix instruction, or three-way bf16 splits on the
-    bf16 matrix cores for K <= 64) and sums that end in float64, against the float64 product."""
+    bf16 matrix cores for K <= 100) and sums that end in float64, against the float64 product."""
     import torch
     from oriana_amd import _lib
     from oriana_amd._lib import call, ptr, stream_ptr
@@ -580,7 +580,7 @@ def test_dense_t_times_factor_f32(n, m, K, arithmetic):
 @pytest.mark.parametrize('arithmetic', [0, 1], ids=['f32', 'bf16x3'])
 def test_dropout_sweep_fused_matches_float64(n, m, K, with_next, arithmetic):
     """oriana_dropout_sweep_fused against the float64 kernels: D_hat, the column sums of p_d, and D_hat V_next, with
-    the float32 matrix instruction and with three-way bf16 splits on the bf16 matrix cores (K <= 64)."""
+    the float32 matrix instruction and with three-way bf16 splits on the bf16 matrix cores (K <= 100)."""
     import torch
     from oriana_amd import _lib
     from oriana_amd._lib import call, ptr, stream_ptr

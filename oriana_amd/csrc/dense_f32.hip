@@ -1088,9 +1088,11 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, pi_d64, m);
     const float *pi_d = scratch;
-    int rc;
-    if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K)) {
+    int rc = ORIANA_EKRANGE;
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K))
         rc = dn::zi_sweep(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, scratch + (m + 63) / 64 * 64, n, m, (int)K, st);
+    if (rc != ORIANA_EKRANGE) {
+        // (done, or failed for good; ORIANA_EKRANGE = not this kernel's case, e.g. a D_hat that is not 16-byte aligned)
     } else if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
         float *img = scratch + (m + 63) / 64 * 64;
         switch ((int)((K + 15) / 16)) {
@@ -1127,9 +1129,10 @@ extern "C" int oriana_dense_t_times_factor_f32(double *out, const float *D, cons
     if (!out || !D || !W) return ORIANA_EINVAL;
     if (arithmetic != ORIANA_MATRIX_F32 && arithmetic != ORIANA_MATRIX_BF16X3) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (arithmetic == ORIANA_MATRIX_BF16X3 && scratch && ((uintptr_t)scratch & 15) == 0 && dn::zi_dt_supported(m, K)) {
+    int rc = ORIANA_EKRANGE;
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && scratch && ((uintptr_t)scratch & 15) == 0 && dn::zi_dt_supported(m, K))
         rc = dn::zi_dt(out, D, W, scratch, n, m, (int)K, st);
+    if (rc != ORIANA_EKRANGE) {
     } else if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
         if (!scratch || ((uintptr_t)scratch & 15) != 0) return ORIANA_EINVAL;
         if (K <= 32) rc = launch_dt_b16<1>(out, D, W, scratch, n, m, (int)K, st);

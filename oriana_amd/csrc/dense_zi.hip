@@ -643,6 +643,7 @@ int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, 
 int zi_dt(double *out, const float *D, const double *W, float *scratch, int64_t n, int64_t m, int K, hipStream_t st) {
     int kc, tl;
     if (!zi_dt_supported(m, K) || !zi_cfg(K, &kc, &tl)) return ORIANA_EKRANGE;
+    if ((reinterpret_cast<uintptr_t>(D) & 15) != 0) return ORIANA_EKRANGE;   // 16-byte row pieces: the caller falls back
     const int ngt = (int)((m + 31) / 32);
     const int64_t nct = (n + 31) / 32;
     const int64_t groups = (ngt + NW - 1) / NW;

@@ -747,3 +747,37 @@ def test_scale_drift_keeps_the_fast_path(eng, shift_u, shift_v, fast):
         # glibc / the device round them differently): both sides reproduce that arithmetic, to ~1e-3
         tol = RTOL if fast else 2e-3
         assert err_colrel(Zi, rZi) < tol and err_colrel(Zj, rZj) < tol
+
+
+@pytest.mark.gpu
+def test_dense_zi_kernels_decline_unaligned_buffers():
+    """csrc/dense_zi.hip moves 16-byte pieces: a D_hat that starts 4 bytes off a 16-byte boundary takes the float32
+    instruction's kernels instead (same results to float32 accuracy), through both entries."""
+    import torch
+    from oriana_amd import _lib
+    from oriana_amd._lib import call, ptr, stream_ptr
+    n, m, K = 300, 260, 100
+    g = torch.Generator(device='cpu').manual_seed(3)
+    U = (torch.rand(n, K, generator=g, dtype=torch.float64) * 0.3).cuda()
+    V = (torch.rand(m, K, generator=g, dtype=torch.float64) * 0.3).cuda()
+    pi = torch.rand(m, generator=g, dtype=torch.float64).cuda()
+    X = (torch.rand(n, m, generator=g) < 0.2).float().cuda()
+    mask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device='cuda')
+    call('oriana_nzmask_f32', ptr(mask), ptr(X), n, m, stream_ptr())
+    lgs = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
+    dts = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device='cuda')
+    outs = []
+    for shift in (0, 1):
+        base = torch.zeros(n * m + 4, dtype=torch.float32, device='cuda')
+        D = base[shift:shift + n * m].view(n, m)
+        assert (D.data_ptr() % 16 == 0) == (shift == 0)
+        cs = torch.zeros(m, dtype=torch.float64, device='cuda')
+        DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
+        call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(DV), ptr(lgs), 1,
+             n, m, K, stream_ptr())
+        DtU = torch.zeros(m, K, dtype=torch.float64, device='cuda')
+        call('oriana_dense_t_times_factor_f32', ptr(DtU), ptr(D), ptr(U), ptr(dts), 1, n, m, K, stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((D.clone(), cs, DV, DtU))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.allclose(a.double(), b.double(), rtol=2e-6, atol=1e-7)

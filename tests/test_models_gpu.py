@@ -198,11 +198,44 @@ def test_oracle_agreement_multi_tile(name):
         assert_state_close(G.state(), O.state(), what='%s sweep %d' % (name, it), exact=E.state() if E is not None else None)
 
 
+@pytest.mark.parametrize('K', [33, 50, 68, 84, 100])
+@pytest.mark.parametrize('name', ['ZIGaP', 'SparseZIGaP'])
+def test_zi_models_on_the_pipelined_dense_kernels(name, K):
+    """The same three sweeps with a gene count that is a multiple of 4, where 33 <= K <= 100 runs on csrc/dense_zi.hip
+    (every (KC, TAIL) pair), on counts with a gene expressed in EVERY cell (pi_d must come out as 1 - 1e-10 with a finite
+    logit, zigap.py:135, 158 -- not as 1, which would switch the column to the pi_d >= 1 override) and a gene expressed in
+    none (both columns were untested)."""
+    import oriana_amd.models as M
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(100 + K)
+    n, m = 300, 272
+    X = (rng.poisson(3.0, size=(n, m)) * (rng.random((n, m)) < 0.25)).astype(np.int64)
+    X[:, 0] = rng.poisson(3.0, size=n) + 1
+    X[:, 5] = 0
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    G = getattr(M, name)(X, k=K, init=(a1, b1))
+    O = co.MODELS[name](X, K, a1, b1)
+    for it in range(3):
+        O.load_state(G.state())
+        O.D_hat = G.D_hat.copy()
+        E = exact_twin(O) if O.sparse else None
+        G.step(); O.step()
+        if E is not None:
+            E.step()
+        assert_state_close(G.state(), O.state(), what='%s K=%d sweep %d' % (name, K, it),
+                           exact=E.state() if E is not None else None)
+        pi = G.pi_d.asarray()
+        assert pi[0] < 1.0 and abs(pi[0] - (1.0 - 1e-10)) < 1e-12, pi[0]
+        assert np.all(G.D_hat[:, 0] == 1.0) and 0.0 < pi[5] < 1.0
+    assert G.n_kept_products == 2
+
+
 @pytest.mark.parametrize('K', [1, 33, 64, 65, 100, 128, 129])
 @pytest.mark.parametrize('name', ['ZIGaP', 'SparseZIGaP'])
 def test_zi_models_across_matrix_kernel_boundaries(name, K):
-    """The ZI sweeps at the K where the dense kernels change: bf16 x 3 up to 64, the float32 matrix instruction up to
-    128, the float64 kernels above; the fused sparse passes up to 64.  Three HIP sweeps (the second and third use the
+    """The ZI sweeps at the K where the dense kernels change (a gene count that is NOT a multiple of 4: dense_f32.hip
+    throughout): bf16 x 3 up to 64, the float32 matrix instruction up to 128, the float64 kernels above; the fused sparse
+    passes up to 64.  Three HIP sweeps (the second and third use the
     product kept by the previous D update), each against the oracle sweep started from the same state."""
     import oriana_amd.models as M
     from oracle import cavi_oracle as co

@@ -583,7 +583,7 @@ static int64_t zi_pick_splits(int64_t blocks, int64_t max_splits) {
         else return ORIANA_EKRANGE;                                           \
     } while (0)
 
-// Smallest K served here: 33.  Measured at 100k x 20k against dense_f32.hip's bf16 kernels (tools/perf_zi_dense.py): D update
+// Smallest K served here: 33.  Measured at 100k x 20k against dense_f32.hip's bf16 kernels (tools/perf_zi_per_k.py): D update
 // 3.45 against 4.11 ms at K = 48, 3.82 against 4.00 ms at K = 50; D^T U 1.82 against 2.00 ms at K = 48 but 2.06 against
 // 1.98 ms at K = 50 (the tail factors' 4 x 4 x 1 instructions): below 65 the transposed product comes here only when Kp has
 // no tail.  ORIANA_ZI_DN_MINK raises the limit for A/B measurements (65: round 2's assignment).

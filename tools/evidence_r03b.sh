@@ -23,8 +23,8 @@ python3 tools/trace_sweep.py $O/trace_c2/c2_results.db > $O/c2_sweep_timeline.tx
 python3 tools/host_vs_gpu.py > $O/c2_host_vs_gpu.txt 2>&1
 python3 tools/perf_small.py > $O/perf_small.txt 2>&1
 ORIANA_PASS_IMPL=r2 python3 tools/perf_small.py > $O/perf_small_r2kernels.txt 2>&1
-python3 tools/perf_zi_dense.py 100000 20000 40 48 50 64 65 80 84 96 100 128 > $O/zi_dense_per_k.txt 2>&1
-ORIANA_ZI_DN_MINK=1000 python3 tools/perf_zi_dense.py 100000 20000 40 48 50 80 100 > $O/zi_dense_per_k_round2_kernels.txt 2>&1
+python3 tools/perf_zi_per_k.py 100000 20000 40 48 50 64 65 80 84 96 100 128 > $O/zi_dense_per_k.txt 2>&1
+ORIANA_ZI_DN_MINK=1000 python3 tools/perf_zi_per_k.py 100000 20000 40 48 50 80 100 > $O/zi_dense_per_k_round2_kernels.txt 2>&1
 timeout 1500 python3 tools/run_models.py ZIGaP 1000000 30000 100 > $O/zigap_c4shape_k100.txt 2>&1
 timeout 600 python3 tools/parity_report.py $O/parity_errors.json > $O/parity.txt 2>&1
 for f in $O/bench_*.json; do python3 -c "

@@ -1,57 +1,63 @@
 # -*- coding: utf-8 -*-
-"""The two dense contractions of a ZI sweep (D update + next D_hat V; D_hat^T U) per arithmetic: ms and ps per entry.
-   python tools/perf_zi_dense.py n m K [K ...]        (GPU)"""
+"""Times the dense kernels of a ZI sweep on synthetic operands: the float32 matrix-core path (csrc/dense_f32.hip)
+next to the float64 one (csrc/dense_mfma.hip).   python3 tools/perf_zi_dense.py [n m K]   (default: configs[2])"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oriana_amd import _lib                         # noqa: E402
 from oriana_amd._lib import call, ptr, stream_ptr   # noqa: E402
 
+n, m, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (100000, 20000, 50)
+dev = torch.device('cuda')
+g = torch.Generator(device=dev).manual_seed(1)
+D = torch.rand(n, m, generator=g, device=dev)
+U = torch.rand(n, K, generator=g, device=dev, dtype=torch.float64) * 0.5
+V = torch.rand(m, K, generator=g, device=dev, dtype=torch.float64) * 0.5
+pi = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
+mask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device=dev)
+call('oriana_nzmask_f32', ptr(mask), ptr((D < 0.1).float()), n, m, stream_ptr())
+cs = torch.zeros(m, dtype=torch.float64, device=dev)
+o1 = torch.zeros(n, K, dtype=torch.float64, device=dev)
+o2 = torch.zeros(m, K, dtype=torch.float64, device=dev)
+from oriana_amd import _lib   # noqa: E402
+lgs = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device=dev)
 
-def timed(fn, reps=5):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
+
+def timeit(f, reps=5):
+    f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+        f()
+    e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
 
-def main():
-    n, m = int(sys.argv[1]), int(sys.argv[2])
-    dev = 'cuda'
-    g = torch.Generator(device=dev).manual_seed(1)
-    X = (torch.rand(n, m, device=dev, generator=g) < 0.1).float()
-    mask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device=dev)
-    call('oriana_nzmask_f32', ptr(mask), ptr(X), n, m, stream_ptr())
-    D = X                                                  # (overwritten by the sweep: the non-zeros stay 1)
-    lib = _lib.load()
-    for K in [int(a) for a in sys.argv[3:]]:
-        U = torch.rand(n, K, dtype=torch.float64, device=dev, generator=g) * 0.2
-        V = torch.rand(m, K, dtype=torch.float64, device=dev, generator=g) * 0.2
-        pi = torch.rand(m, dtype=torch.float64, device=dev, generator=g)
-        cs = torch.zeros(m, dtype=torch.float64, device=dev)
-        DV = torch.zeros(n, K, dtype=torch.float64, device=dev)
-        out = torch.zeros(m, K, dtype=torch.float64, device=dev)
-        lgs = torch.zeros(int(lib.oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device=dev)
-        dts = torch.zeros(int(lib.oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device=dev)
-        res = []
-        for arith, name in ((1, 'bf16x3'), (0, 'f32')):
-            ts = timed(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V),
-                                    ptr(DV), ptr(lgs), arith, n, m, K, stream_ptr()))
-            td = timed(lambda: call('oriana_dense_t_times_factor_f32', ptr(out), ptr(D), ptr(U), ptr(dts), arith, n, m, K,
-                                    stream_ptr()))
-            res.append('%s: D update %.2f ms (%.2f ps/entry), D^T U %.2f ms (%.2f ps/entry)' % (
-                name, ts, ts * 1e9 / (n * m), td, td * 1e9 / (n * m)))
-        print('n=%d m=%d K=%d | %s' % (n, m, K, ' | '.join(res)), flush=True)
-
-
-if __name__ == '__main__':
-    main()
+st = stream_ptr()
+rows = []
+if K <= 64:
+    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), 1, n, m, K, st))
+    rows.append(('bf16x3  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K + 31) // 32)) / t / 1e9, 4.0 * n * m / t / 1e9))
+t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), 0, n, m, K, st))
+rows.append(('f32  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K + 31) // 32)) / t / 1e9, 4.0 * n * m / t / 1e9))
+if '--shipped-only' not in sys.argv:       # (counter runs: only the two kernels a sweep launches)
+    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), None, None, ptr(lgs), 0, n, m, K, st))
+    rows.append(('f32  D update alone', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
+scr = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device=dev)
+if K <= 64:
+    t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), ptr(scr), 1, n, m, K, st))
+    rows.append(('bf16x3  D^T U', t, 2.0 * n * m * 32 * ((K + 31) // 32) / t / 1e9, 4.0 * n * m / t / 1e9))
+t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), ptr(scr), 0, n, m, K, st))
+rows.append(('f32  D^T U', t, 2.0 * n * m * 32 * ((K + 31) // 32) / t / 1e9, 4.0 * n * m / t / 1e9))
+if '--f64' in sys.argv:
+    t = timeit(lambda: call('oriana_dropout_update_fused', None, ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), n, m, K, st))
+    rows.append(('f64  D update', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
+    t = timeit(lambda: call('oriana_dense_times_factor', ptr(o1), ptr(D), ptr(V), n, m, K, 0, st))
+    rows.append(('f64  D V', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
+    t = timeit(lambda: call('oriana_dense_times_factor', ptr(o2), ptr(D), ptr(U), n, m, K, 1, st))
+    rows.append(('f64  D^T U', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
+print('%d x %d, K = %d' % (n, m, K))
+for name, t, tf, tb in rows:
+    print('%-36s %7.2f ms   %6.1f TFLOP/s issued   D_hat traffic %.2f TB/s' % (name, t, tf, tb))

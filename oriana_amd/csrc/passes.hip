@@ -2055,10 +2055,10 @@ extern "C" int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t 
     KCfg cfg;
     if (!cm || !pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 1;
     const int64_t groups = cm->nrb * ((use_k100(cfg.G, cfg.T4) || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (256 / (16 * (64 / cfg.G))));
-    if (groups >= 256) return 1;
+    static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
+    if (groups >= 256 && forced <= 0) return 1;
     // two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20: 77 / 42 / 25 / 24 us
     // for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
-    static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
     int64_t sp = forced > 0 ? forced : 512 / groups;
     if (sp > cm->ncb) sp = cm->ncb;
     if (sp < 1) sp = 1;

@@ -508,6 +508,8 @@ class ZWorkspace:
             self.dn_imgU = torch.empty(max((ct.n + 31) // 32, 1) * pu * 4, **f32)
             nblk = max(d.nct // 8, 1)
             self.dn_gene_splits = max(1, min(d.ngt, -(-512 // nblk)))
+            if os.environ.get('ORIANA_DN_GENE_SPLITS'):                     # tuning runs
+                self.dn_gene_splits = max(1, min(d.ngt, int(os.environ['ORIANA_DN_GENE_SPLITS'])))
             groups = (d.ngt + 7) // 8
             self.dn_cell_splits = max(1, min((ct.n + 31) // 32, (-(-1024 // groups) + 7) // 8 * 8))
 

@@ -14,7 +14,7 @@ from perf_small import timed                        # noqa: E402
 
 def main():
     dev = 'cuda'
-    for r, K in ((10000, 20), (2000, 20), (125000, 100), (30000, 100)):
+    for r, K in ((10000, 20), (2000, 20), (125000, 100), (30000, 100), (1000000, 100)):
         Kp = engine.kpad(K)
         F = torch.rand(r, Kp, device=dev); R = torch.rand(r, Kp, device=dev) * 50
         Z = torch.zeros(r, K, device=dev)

@@ -93,7 +93,8 @@ def test_zi_sweeps_float32_matrix_path_against_float64(path):
     g = load_golden(path)
     fast, exact = _make(g), _make(g)
     exact._fast_dense = False
-    assert fast._fast_dense
+    if not fast._fast_dense:
+        pytest.skip('ORIANA_ZI_EXACT=1: there is no float32 matrix path to compare')
     for sweep in range(1, 4):
         fast.step(); exact.step()
         assert exact.n_kept_products == 0 and fast.n_kept_products == sweep - 1     # first sweep: nothing to keep yet
@@ -227,7 +228,7 @@ def test_zi_models_on_the_pipelined_dense_kernels(name, K):
         pi = G.pi_d.asarray()
         assert pi[0] < 1.0 and abs(pi[0] - (1.0 - 1e-10)) < 1e-12, pi[0]
         assert np.all(G.D_hat[:, 0] == 1.0) and 0.0 < pi[5] < 1.0
-    assert G.n_kept_products == 2
+    assert G.n_kept_products == (2 if G._fast_dense else 0)
 
 
 @pytest.mark.parametrize('K', [1, 33, 64, 65, 100, 128, 129])
@@ -254,7 +255,7 @@ def test_zi_models_across_matrix_kernel_boundaries(name, K):
             E.step()
         assert_state_close(G.state(), O.state(), what='%s K=%d sweep %d' % (name, K, it),
                            exact=E.state() if E is not None else None)
-    assert G.n_kept_products == (2 if K <= 128 else 0)
+    assert G.n_kept_products == (2 if (K <= 128 and G._fast_dense) else 0)
 
 
 def test_config2_full_size_properties():
@@ -638,7 +639,8 @@ def test_config3_zi_slab_against_float64_oracle():
     ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, 'cuda')
     a1, b1 = gen.initial_shapes()
     model = ZIGaP(ct, k=K, init=(a1, b1), device='cuda')
-    assert model._fast_dense and model._matrix_arith == 1
+    if not (model._fast_dense and model._matrix_arith == 1):
+        pytest.skip('the default (bf16 x 3) dense arithmetic is switched off (ORIANA_ZI_MATRIX / ORIANA_ZI_EXACT)')
     model.step(); model.step()
     Xs = np.ascontiguousarray(gen.chunk(0, sl).cpu().numpy().astype(np.float32))
     lu = np.ascontiguousarray(model._log_U_hat[:sl].cpu().numpy()); lv = np.ascontiguousarray(model._log_V_hat.cpu().numpy())
@@ -798,6 +800,8 @@ def test_sparse_zi_at_config3_shape_against_float64_kernels():
     ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, 'cuda')
     a1, b1 = gen.initial_shapes()
     fast = SparseZIGaP(ct, k=K, init=(a1, b1), device='cuda')
+    if not (fast._fast_dense and engine._FUSE_SPARSE_ROWS and engine._FUSE_SPARSE_COLS):
+        pytest.skip('a switch (ORIANA_ZI_EXACT / ORIANA_SPARSE_ROWS / ORIANA_SPARSE_COLS) turns the compared path off')
     fast.fit(3)
     assert fast.n_kept_products == 2 and fast._ws.s_rs is None
     fused = (engine._FUSE_SPARSE_ROWS, engine._FUSE_SPARSE_COLS)

@@ -138,16 +138,56 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # ORIANA_BENCH_FORCE_PG=1 (rehearsal of the RCCL path on a 1-GPU box, tests/test_sharded_gpu.py): a process group of
+    # ONE rank on the nccl backend, and ORIANA_FORCE_SHARDED=1 makes the sweep issue every collective (self all-reduces)
+    force_pg = world == 1 and os.environ.get('ORIANA_BENCH_FORCE_PG') == '1'
+    if force_pg:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ['ORIANA_FORCE_SHARDED'] = '1'
+    if world > 1 or force_pg:
         if one_gpu:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
 
+    out = measure(args, args.workload, args.steps, args.warmup, world, rank, dev, np, torch, dist,
+                  cpu_rows=(None if args.no_cpu else args.cpu_rows))
+    if rank == 0:
+        # The other single-GPU configurations of BASELINE.json ride in the SAME json line (so that the driver's run, not
+        # only profiles/, carries them): configs[2] (ZI-pCMF) and configs[4] (sparse pCMF), a short run each after the
+        # headline measurement, with their own roofline objects and parity slabs.  ORIANA_BENCH_SECONDARY=0 skips them.
+        if (world == 1 and args.workload == 'c4' and not args.no_cpu
+                and os.environ.get('ORIANA_BENCH_SECONDARY', '1') != '0'):
+            out['secondary_workloads'] = []
+            for wl in ('c3_zi', 'c5_sparse'):
+                try:
+                    sub = measure(args, wl, 10, 3, world, rank, dev, np, torch, dist, cpu_rows=400, brief=True)
+                except Exception as exc:            # never let an extra figure break the bench line
+                    sub = {'workload': wl, 'error': repr(exc)[:300]}
+                out['secondary_workloads'].append(sub)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1 or force_pg:
+        dist.destroy_process_group()
+
+
+def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cpu_rows=None, brief=False):
+    """One workload: setup, warm-up, the timed sweeps, the pass timings, the roofline object, the CPU baseline and the
+    parity slab.  Returns the dict of the bench line (rank 0; None elsewhere).  `cpu_rows`: None = no CPU leg, 0 = sized
+    for ~15 s of single-thread work, else the rows of the sample.  `brief`: a secondary workload (short keys only)."""
     from oriana_amd import engine, dist as odist
     import oriana_amd.models as models
     from oriana_amd.singlecell import SyntheticCounts
 
+    class _A:                                   # the loop below reads args.steps / args.warmup / args.workload
+        pass
+    a = _A()
+    a.__dict__.update(vars(args))
+    a.steps, a.warmup, a.workload = steps, warmup, workload
+    args = a
     mname, n_total, m, K, z, cfg_label = WORKLOADS[args.workload]
     r0, r1 = odist.shard_rows(n_total, rank, world)
     n = r1 - r0
@@ -158,11 +198,11 @@ def main():
     if mname == 'GaP' and engine.dense_supported(K):
         dd = engine.auto_dense_density(n_total, m, K) if args.dense_density == 'auto' else (float(args.dense_density) or None)
     counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
-                                           reduce_fn=(lambda t: odist.all_reduce_sum(t)) if world > 1 else None,
+                                           reduce_fn=(lambda t: odist.all_reduce_sum(t)) if (world > 1 or odist.sharded()) else None,
                                            dense_density=dd, n_total=n_total)
     a1, b1 = gen.initial_shapes()
     model = getattr(models, mname)(counts, k=K, use_factors=False, init=(a1, b1), device=dev,
-                                   process_group=(dist.group.WORLD if world > 1 else None), n_total=n_total)
+                                   process_group=(dist.group.WORLD if (world > 1 or odist.sharded()) else None), n_total=n_total)
     del a1, b1
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -256,11 +296,15 @@ def main():
 
     cpu = None
     slab = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu, slab = cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, args.cpu_rows, dev)
+    if rank == 0 and world == 1 and cpu_rows is not None:
+        cpu, slab = cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, cpu_rows, dev, openmp=not brief)
+    stateless = None
+    if rank == 0 and world == 1 and cpu_rows is not None and mname == 'GaP' and not brief:
+        stateless = stateless_binding_ms(np, torch, engine, model, gen, m, K, dev)
 
     if rank == 0:
         traffic, traffic_src = recorded_traffic(args.workload, world, counts.gd > 0)
+        frac_step = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_per_step > 0 else 0.0
         out = {
             'metric': 'CAVI sweeps/sec (%s, %s x %s, K=%d)' % (MODEL_LABEL[mname], fmt_dim(n_total), fmt_dim(m), K),
             'value': value, 'unit': 'sweeps/s',
@@ -275,13 +319,16 @@ def main():
                        'n_cells': n_total, 'n_genes': m, 'K': K, 'nnz': nnz_total, 'rows_per_rank': n,
                        'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1),
                        'hbm_gb_rank0': round(torch.cuda.max_memory_allocated() / 1e9, 1),
-                       'collectives_per_sweep': (2 + (1 if model.zi else 0)) if world > 1 else 0,
+                       'collectives_per_sweep': (2 + (1 if model.zi else 0)) if (world > 1 or odist.sharded()) else 0,
                        'layout': ('hybrid: %d genes (expressed in >= %.0f%% of the cells, %.1f%% of the non-zeros) as a dense block on the '
                                   'bf16 matrix cores (float32-equivalent: exact three-way splits, six cross products), %d genes sliced'
                                   % (counts.gd, 100.0 * counts.dense_density, 100.0 * counts.dense.nnz / max(counts.nnz, 1), counts.ms))
                                  if counts.gd else 'sliced non-zero layout'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'frac': achieved / HBM_PEAK_GBS,
+                         # the same algorithmic bytes over the WHOLE sweep's wall time (updates, launches and gaps included)
+                         'frac_step': frac_step,
+                         'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'the pass of one sweep on rank 0: ' + ' + '.join(k for k in pass_names if k in ks),
                          'algorithmic_bytes': alg_bytes, 'design_bytes': design_bytes,
                          'kernel_ms': {k: ks[k] for k in pass_names if k in ks},
@@ -292,7 +339,7 @@ def main():
                          # what binds each kernel of the pass (counters under profiles/r03_*)
                          'limiter_per_kernel': {k: v for k, v in {
                              'row_pass': 'VALU issue + LDS return port (two lanes per row, 400 B of K-vector per slot)',
-                             'col_pass': 'LDS array bandwidth (1 FMA per 4 B read: ~150 B/clk/CU sustained)',
+                             'col_pass': 'VALU issue + LDS return port (issue-bound: masking the padding slots\' reads leaves the time unchanged, DESIGN.md 10 j)',
                              'dense_row': 'matrix pipe + LDS operand reads + VALU (splits, s = x / den), which add up rather than overlap',
                              'dense_col': 'matrix pipe + LDS operand reads + VALU (splits of s); HBM read of s (4 B per entry)',
                              'dense_images': 'HBM (split operand images, (n + gd) K values)', 'fixup': 'rare (exact slow path)'}.items() if k in ks},
@@ -346,10 +393,23 @@ def main():
             out['allreduce_share_of_step'] = allreduce_ms / ms_per_step if ms_per_step > 0 else None
             out['exchange_bytes'] = int(model._xch.numel * 4)
             out['exchange'] = 'one step per sweep: float32 all-reduce of the per-gene sums + float64 all-reduce of the (small) rate partials'
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if world > 1:
-        dist.destroy_process_group()
+        if stateless is not None:
+            out['stateless_binding'] = stateless
+        if world == 1 and odist.sharded():
+            out['exchange_rehearsal'] = {'backend': dist.get_backend(), 'ranks': 1, 'exchanges': int(model._xch.n_reduces),
+                                         'collectives': int(model._xch.n_collectives),
+                                         'what': 'one-rank process group: every collective of the sharded sweep issued as a self all-reduce'}
+        if brief:
+            keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'dtype', 'config',
+                    'roofline', 'parity_slab', 'f64_reference_arithmetic_ms', 'cpu_baseline', 'check')
+            out = {k: out[k] for k in keep if k in out}
+            out['workload'] = workload
+    else:
+        out = None
+    # free the workload before the next one is set up (the headline matrix holds ~65 GB)
+    del model, counts, gen, timer
+    torch.cuda.empty_cache()
+    return out
 
 
 def fmt_dim(v):
@@ -367,7 +427,7 @@ def recorded_traffic(workload, world, hybrid=False):
     if world != 1:
         return None, None
     tag = workload + ('_hybrid' if hybrid else '')
-    for rnd in ('r03', 'r02', 'r01'):
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_hbm_%s.json' % (rnd, tag))
         if os.path.exists(path):
             try:
@@ -378,7 +438,31 @@ def recorded_traffic(workload, world, hybrid=False):
     return None, None
 
 
-def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, rows, dev):
+def stateless_binding_ms(np, torch, engine, model, gen, m, K, dev, rows=2048):
+    """The drop-in kernel boundary as INTEGRATION.md section B binds it (oriana_zq_gap_f32: dense float32 device
+    matrices in the reference's argument order, no resident state): every call packs X into the sliced layout, runs the
+    pass and synchronises.  Timed once here so that the figure exists: ms per call on the first `rows` cells."""
+    rows = min(rows, gen.n)
+    X = gen.chunk(0, rows).to(torch.float32).contiguous()
+    lu = model._log_U_hat[:rows].contiguous()
+    lv = model._log_V_hat.contiguous()
+    Zi = torch.empty(rows, K, device=dev); Zj = torch.empty(m, K, device=dev)
+    for _ in range(2):
+        engine.zq_gap_stateless(Zi, Zj, lu, lv, X)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        engine.zq_gap_stateless(Zi, Zj, lu, lv, X)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {'entry': 'oriana_zq_gap_f32 (csrc/stateless.hip)', 'rows': rows, 'genes': m, 'K': K, 'ms_per_call': ms,
+            'dense_x_gb_per_s': 4.0 * rows * m / (ms * 1e-3) / 1e9,
+            'note': 'packs the dense X on every call (sliced layout only, no matrix-core path) and synchronises; the resident '
+                    'model path amortises the packing over the sweeps'}
+
+
+def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, rows, dev, openmp=True):
     """(1) CPU baseline: one FULL sweep of the oracle (oracle/cavi_oracle.py: the C restatement of the loop nest,
     1 thread, + the NumPy/SciPy updates) on the first `rows` cells of the same matrix, extrapolated to n_total
     cells (loop nest linear in the rows; updates linear in rows + genes); BASELINE configs[1] runs in full.
@@ -415,6 +499,8 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
     cores = os.cpu_count() or 1
     omp = None
     try:
+        if not openmp:
+            raise RuntimeError('skipped for a secondary workload')
         # its own, larger sample: 2000 rows would leave 8 rows per thread on a 256-core host
         rows_omp = min(gen.n, n_total, max(rows, min(16384, rows * max(1, cores // 8))))
         Xo = Xf if rows_omp == rows else np.ascontiguousarray(gen.chunk(0, rows_omp).cpu().numpy().astype(np.float32))

@@ -9,10 +9,19 @@ sparsity posteriors and all K-vectors are replicated.  Per sweep the ranks excha
 all-reduce, only the per-gene accumulators (m x K float32) and the column sums of the new U_hat /
 log_U_hat (2 x K float64) -- the U update is row-local, so these partials exist before the V update.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_rows', 'world_size', 'rank', 'all_reduce_sum', 'all_reduce_sum_async', 'sum_int', 'SweepExchange']
+__all__ = ['shard_rows', 'world_size', 'rank', 'sharded', 'all_reduce_sum', 'all_reduce_sum_async', 'sum_int', 'SweepExchange']
+
+
+def _forced():
+    """ORIANA_FORCE_SHARDED=1: a process group of ONE rank takes the sharded code path (every collective of a sweep is
+    really issued -- a self all-reduce).  Rehearsal of the RCCL path on a single-GPU box: bench.py
+    ORIANA_BENCH_FORCE_PG=1, tests/test_sharded_gpu.py."""
+    return os.environ.get('ORIANA_FORCE_SHARDED') == '1'
 
 
 def shard_rows(n_total, rank_, world):
@@ -36,6 +45,13 @@ def world_size(pg=None):
     return dist.get_world_size(pg) if pg is not None else dist.get_world_size()
 
 
+def sharded(pg=None):
+    """True when the collectives of a sweep must be issued: more than one rank, or the one-rank rehearsal mode."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return world_size(pg) > 1 or _forced()
+
+
 def rank(pg=None):
     if not (dist.is_available() and dist.is_initialized()):
         return 0
@@ -44,7 +60,7 @@ def rank(pg=None):
 
 def all_reduce_sum(t, pg=None):
     """In-place sum all-reduce (no-op on a single process)."""
-    if world_size(pg) > 1:
+    if sharded(pg):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
     return t
 
@@ -53,13 +69,13 @@ def all_reduce_sum_async(t, pg=None):
     """Start an in-place sum all-reduce and return a handle with ``wait()`` (None on a single process).
     On RCCL the collective runs on the communicator's own stream, ordered after the work already queued
     on the current stream, so kernels launched between this call and ``wait()`` overlap with it."""
-    if world_size(pg) > 1:
+    if sharded(pg):
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg, async_op=True)
     return None
 
 
 def sum_int(v, pg=None, device=None):
-    if world_size(pg) == 1:
+    if not sharded(pg):
         return int(v)
     t = torch.tensor([int(v)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
@@ -82,6 +98,7 @@ class SweepExchange:
     def __init__(self, device, pg, f32_shapes, f64_shapes):
         self.pg = pg
         self.world = world_size(pg)
+        self.active = sharded(pg)     # False: nothing is packed or reduced (one process, no rehearsal mode)
         self.device = torch.device(device)
         self.n_reduces = 0            # exchanges (one per sweep)
         self.n_collectives = 0        # all-reduce calls: one per exchange and dtype present
@@ -111,7 +128,7 @@ class SweepExchange:
 
     def put64(self, name, t):
         """Stage a float64 tensor of the declared shape (kept as it is on one process)."""
-        if self.world == 1:
+        if not self.active:
             self._local64[name] = t
             return
         o, c, shape = self._seg64[name]
@@ -119,7 +136,7 @@ class SweepExchange:
         self.buf64[o:o + c] = t.reshape(-1)
 
     def get64(self, name, out=None):
-        if self.world == 1:
+        if not self.active:
             t = self._local64[name]
             if out is not None and out is not t:
                 out.copy_(t)
@@ -135,7 +152,7 @@ class SweepExchange:
     def reduce(self, async_op=False):
         """The exchange (no-op on one process): both buffers are handed to the backend back to back (a float64 buffer
         already started by start64() is not sent again).  With async_op the caller must wait()."""
-        if self.world == 1:
+        if not self.active:
             return
         self.n_reduces += 1
         bufs = [self.buf] if self.numel32 else []
@@ -157,7 +174,7 @@ class SweepExchange:
         """Start the float64 all-reduce NOW, asynchronously: its partials (the cell-side column sums, D_hat^T U_hat)
         exist before the column pass, which then runs under it; reduce() later sends the float32 buffer only and
         waits for both."""
-        if self.world == 1 or not self.numel64:
+        if not self.active or not self.numel64:
             return
         self.n_collectives += 1
         self._pending.append(dist.all_reduce(self.buf64, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

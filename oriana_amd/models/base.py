@@ -85,12 +85,13 @@ class FactorModel:
         self.seed = int(seed)
         self.pg = process_group
         self.world = odist.world_size(process_group)
+        self.sharded = odist.sharded(process_group)     # (also the one-rank rehearsal mode, dist._forced)
 
         X_host = None
         # Under row sharding every rank must pack the genes in the SAME internal order (the replicated
         # gene-side matrices of the on-device NMF start live in packed order): the per-gene counts that
         # define the order are summed over the shards.
-        rf = (lambda t: odist.all_reduce_sum(t, process_group)) if self.world > 1 else None
+        rf = (lambda t: odist.all_reduce_sum(t, process_group)) if self.sharded else None
         dd = self._dense_density(dense_density, cmatrix, n_total, init)
         if isinstance(cmatrix, engine.CountTiles):
             self.counts = cmatrix
@@ -240,7 +241,7 @@ class FactorModel:
         """Capture one sweep into a hipGraph and replay it from step() on (single process only:
         the launches of a sweep have no host-side decision, so small problems stop being
         launch-bound).  The state tensors are updated in place, exactly as without the graph."""
-        if self.world > 1:
+        if self.sharded:
             raise RuntimeError('graph capture is for single-process models (collectives are not captured)')
         if self.zi:
             # the lazy p_d of the ZI models is host-side state (snapshot + deferred evaluation) that a replayed

@@ -28,7 +28,7 @@ class GaP(FactorModel):
         if self._v_sums_in_acc:                # an E-step without the M-step before it: sum_j V_hat is still in scratch
             self._sumV.copy_(self._accV)
             self._v_sums_in_acc = False
-        fold_cols = self.world == 1            # (under row sharding Z_j is completed per rank, then exchanged)
+        fold_cols = not self.sharded           # (under row sharding Z_j is completed per rank, then exchanged)
         engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows', finalize_rows=False,
                       clear=(self._sumU, self._accV))
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102

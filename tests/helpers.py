@@ -21,10 +21,11 @@ RTOL = 1e-5   # BASELINE.json north_star: "within 1e-5 relative on the variation
 KEY_ATOL = {'p_d': 2e-6, 'pi_d': 1e-7}
 # The sparsity posterior p_s = sigmoid(logit(pi_s) - t), t a float32 difference of two sums of magnitude 1e4..1e6,
 # is judged against the EXACT value of the same sweep wherever a test can compute it (exact_twin below: HIP within
-# 7.1e-6, the reference's own arithmetic within 2.0e-6); 1e-4 is only the fallback for comparisons of untouched
-# initial states.
-KEY_RTOL = {'p_s': 1e-4, 'pi_s': 1e-4, 'S_hat': 1e-4}
-
+# 7.1e-6, the reference's own arithmetic within 2.0e-6).  Where it cannot (the NMF-start goldens, whose float32 loop
+# underflows where float64 does not), the bound against the reference's state is 2 x the worst error achieved over all
+# goldens and sweeps (profiles/r03_parity_errors.json: p_s, S_hat 5.8e-6 in the column metric; pi_s 5.4e-7, i.e. inside
+# RTOL without an entry here).  Round 3 allowed 1e-4.
+KEY_RTOL = {'p_s': 1.2e-5, 'S_hat': 1.2e-5}
 
 def golden_files(pattern='*_*.npz'):
     skip_metrics = not pattern.startswith('metrics_')
@@ -78,8 +79,8 @@ def exact_twin(oracle_model):
     return E
 
 
-PS_FLOOR = {'p_s': 2e-5, 'S_hat': 2e-5, 'pi_s': 3e-6}     # absolute, against the EXACT value (measured worst: 7.1e-6 / 1.0e-6)
-PS_FACTOR = 16.0                                           # ... or this many times the reference's own distance from exact
+PS_FLOOR = {'p_s': 1.4e-5, 'S_hat': 1.4e-5, 'pi_s': 2e-6}   # absolute, against the EXACT value: 2 x the measured worst (7.1e-6 / 1.0e-6)
+PS_FACTOR = 8.0                                            # ... or this many times the reference's own distance from exact (<= 2.0e-6)
 
 
 def assert_state_close(got, ref, rtol=RTOL, keys=None, what='', exact=None):

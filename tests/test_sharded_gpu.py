@@ -263,3 +263,33 @@ def test_bench_self_launch_two_ranks():
     assert len(d['per_rank_ms']['ranks']) == 2 and d['allreduce_ms'] > 0
     assert d['exchange_bytes'] == (30000 * 100 + 4 * 100) * 4
     assert 'K=100' in d['metric'] and '125k' in d['metric']
+
+
+def test_rccl_single_rank_rehearsal():
+    """The RCCL path itself, on the one GPU a test box has: `bench.py --gpus 1` with ORIANA_BENCH_FORCE_PG=1 initialises the
+    nccl backend (= RCCL) with device_id= exactly as a multi-GPU launch does (bench.py main), and ORIANA_FORCE_SHARDED=1 makes
+    the sweep take the sharded code path with a process group of ONE rank -- the counts' all-reduce at packing, the
+    asynchronous float64 all-reduce started before the column pass, the float32 all-reduce of Z_j after it, wait(): every
+    collective is really issued (a self all-reduce).  Same sweeps, same `check` as the plain single-process run."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'ORIANA_FORCE_SHARDED', 'ORIANA_BENCH_FORCE_PG'):
+        base.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1', '--workload', 'c2',
+           '--no-cpu']
+    out = {}
+    for tag, extra in (('plain', {}), ('rccl', {'ORIANA_BENCH_FORCE_PG': '1', 'MASTER_PORT': str(_free_port())})):
+        r = subprocess.run(cmd, env=dict(base, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out[tag] = json.loads(lines[0])
+    d = out['rccl']
+    assert d['exchange_rehearsal']['backend'] == 'nccl' and d['exchange_rehearsal']['ranks'] == 1
+    # 1 warm-up + 4 timed sweeps, each one exchange of two collectives (float64 partials, float32 per-gene sums)
+    assert d['exchange_rehearsal']['exchanges'] == 5 and d['exchange_rehearsal']['collectives'] == 10
+    assert d['config']['collectives_per_sweep'] == 2
+    assert 'exchange_rehearsal' not in out['plain']
+    assert abs(d['check'] / out['plain']['check'] - 1.0) < 1e-6

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -119,13 +120,18 @@ __global__ __launch_bounds__(256) void k_valu(float *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = v0.x + v1.x + v2.y + v3.x + v4.x + v5.y + v6.x + v7.x;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // `errors`: only part (1), at 64 / 256 / 512 terms, every length on its own seed (tests/test_ubench_gpu.py checks the
+    // printed figures against their bounds: the float32-equivalence of the bf16 x 3 evaluation is re-measured every round)
+    const bool errors_only = argc > 1 && std::string(argv[1]) == "errors";
     float *dA, *dB, *dC, *out;
     const int SMAX = 256;
     (void)hipMalloc(&dA, 32 * 16 * SMAX * 4); (void)hipMalloc(&dB, 32 * 16 * SMAX * 4); (void)hipMalloc(&dC, 1024 * 4);
     (void)hipMalloc(&out, 2048 * 256 * 4);
     srand(7);
-    for (int S : {4, 32, 256}) {
+    const std::vector<int> lengths = errors_only ? std::vector<int>{4, 16, 32} : std::vector<int>{4, 32, 256};
+    for (int S : lengths) {
+        if (errors_only) srand(7 + S);
         std::vector<float> A(32 * 16 * S), B(16 * S * 32), C(1024);
         for (auto &v : A) { v = (float)rand() / RAND_MAX; if (rand() % 4 == 0) v *= 1e-4f; }    // D_hat-like: [0, 1], some tiny
         for (auto &v : B) v = 0.01f + 3.f * (float)rand() / RAND_MAX;
@@ -144,6 +150,7 @@ int main() {
         printf("%5d terms: bf16x3 (6 products): mean signed rel err %+.3e  rms %.3e  max %.3e   | float32 fma chain rms %.3e\n",
                16 * S, bias / 1024, sqrt(rms / 1024), mx, sqrt(rms32 / 1024));
     }
+    if (errors_only) return 0;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     auto timeit = [&](auto launch) { float ms = 0; for (int rep = 0; rep < 3; ++rep) { (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); } return ms; };
     const int iters = 4000;

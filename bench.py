@@ -73,16 +73,20 @@ def self_launch(args):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    import tempfile
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        ef = tempfile.TemporaryFile(mode='w+')          # the rank's stderr: replayed below, summarised on failure
+        errs.append(ef)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=ef))
     # poll: the first rank to fail takes its siblings down (they would otherwise block in their next collective until
     # the driver's limit); overall limit ORIANA_BENCH_TIMEOUT_S (default 3000 s).  Fresh children only are ever started
     # or killed -- this process has not touched the GPU.
     deadline = time.time() + float(os.environ.get('ORIANA_BENCH_TIMEOUT_S', '3000'))
     rc = 0
+    first_bad = None
     live = list(procs)
     while live:
         for p in list(live):
@@ -91,6 +95,7 @@ def self_launch(args):
                 live.remove(p)
                 if r != 0 and rc == 0:
                     rc = r
+                    first_bad = procs.index(p)
         if live and (rc != 0 or time.time() > deadline):
             if rc == 0:
                 rc = 124
@@ -105,6 +110,21 @@ def self_launch(args):
             break
         if live:
             time.sleep(0.2)
+    # every rank's stderr, then (on failure) one line per rank: its exit code and the last line it wrote
+    tails = []
+    for r, ef in enumerate(errs):
+        ef.seek(0)
+        text = ef.read()
+        ef.close()
+        if text:
+            sys.stderr.write(text if text.endswith('\n') else text + '\n')
+        lines = [l for l in text.splitlines() if l.strip()]
+        tails.append(lines[-1][:300] if lines else '')
+    if rc != 0:
+        for r, p in enumerate(procs):
+            code = p.poll()
+            why = 'timeout' if rc == 124 and first_bad is None else ('first to fail' if r == first_bad else 'stopped after rank %s failed' % first_bad if code not in (0, None) else 'ok')
+            sys.stderr.write('[bench] rank %d rc=%s (%s): %s\n' % (r, code, why, tails[r]))
     sys.exit(rc)
 
 

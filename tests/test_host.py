@@ -160,3 +160,23 @@ def test_hybrid_auto_threshold(monkeypatch):
     assert engine.auto_dense_density(1_000_000, 30_000, 100) == 0.3
     monkeypatch.setenv('ORIANA_DENSE_DENSITY', 'off')
     assert engine.auto_dense_density(1_000_000, 30_000, 100) is None
+
+
+def test_bench_self_launch_reports_every_rank():
+    """`python bench.py --gpus 2` without a launcher starts its ranks itself; when one fails, the parent stops the others
+    and says, per rank, its exit code and the last line it wrote (here: no GPU in the build container, so both fail at
+    torch.cuda.set_device)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a host without a GPU (the ranks must fail)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--workload', 'c2', '--no-cpu'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    tail = [l for l in r.stderr.splitlines() if l.startswith('[bench] rank ')]
+    assert len(tail) == 2 and 'rank 0 rc=' in tail[0] and 'rank 1 rc=' in tail[1], r.stderr[-1500:]
+    assert any('first to fail' in l for l in tail)

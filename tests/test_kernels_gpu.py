@@ -781,3 +781,41 @@ def test_dense_zi_kernels_decline_unaligned_buffers():
         outs.append((D.clone(), cs, DV, DtU))
     for a, b in zip(outs[0], outs[1]):
         assert torch.allclose(a.double(), b.double(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('K', [33, 36, 40, 48, 50, 52, 57, 64])
+@pytest.mark.parametrize('m', [250, 700])
+def test_k64_kernels_shapes(eng, K, m):
+    """The 33 <= Kp <= 64 kernels (two lanes per row / column, image rows zero-padded to 64 floats, two column tiles per
+    image): every padded width (36, 48, 52, 64), one and three column tiles (a pair with a missing second tile), ragged
+    row blocks -- the pCMF nest, then the sparse nest through the fused row pass (second image) and the dual column
+    pass, with a dead gene and per-entry weights."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(K * 11 + m)
+    n = 777
+    X = ((rng.poisson(2.0, size=(n, m)) + 1) * (rng.random((n, m)) < rng.beta(1.0, 2.0, size=m))).astype(np.float32)
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X.astype(np.int64), lu, lv)
+    assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
+    np.testing.assert_allclose(Zi.sum(1), X.sum(1), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(Zj.sum(1), X.sum(0), rtol=2e-5, atol=1e-3)
+    # sparse nest (sparse_gap.py:81-97 / sparse_zigap.py:100-116 with general D_hat)
+    ps = rng.random((m, K))
+    St = (ps > 0.3).astype(np.float32); Sh = ps.astype(np.float32)
+    St[7] = 0
+    lu2 = lu.copy(); lu2[3] -= 80.0                    # a cell on the exact slow path
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    for weighted in (False, True):
+        D = rng.random((n, m)).astype(np.float32) if weighted else None
+        ct = eng.CountTiles.from_dense(c(X), 'cuda', side=(c(D) if weighted else None))
+        ws = eng.ZWorkspace(ct, K)
+        o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+        eng.zq(ws, o[0], o[1], o[2], c(lu2), c(lv), S_tilde=c(St), S_hat=c(Sh), w_nz=(ct.side_nz if weighted else None))
+        r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+        if weighted:
+            co.zq_sparse_zigap(r[0], r[1], r[2], lu2, lv, St, Sh, D, X)
+        else:
+            co.zq_sparse_gap(r[0], r[1], r[2], lu2, lv, St, Sh, X)
+        for got, ref in zip(o, r):
+            assert err_colrel(got.cpu().numpy(), ref) < RTOL
+        assert not o[1].cpu().numpy()[7].any()

@@ -570,7 +570,7 @@ def test_config4_full_size_properties(dense_density):
     gene sum_k Z_j[j, k] = sum_i X[i, j] (gap.py:72-80: the responsibilities of an entry sum to its
     count), plus one full sweep of the model staying finite and conserving the same sums.
     `hybrid`: the layout bench.py measures -- the 4064 genes expressed in >= 20 % of the cells as a dense uint16 block
-    (8 GB of counts, 16 GB of s, [cell tile][gene tile][1024] offsets beyond 2^32) on the matrix-core kernels; on top of
+    (8 GB of counts, 16 GB of s, [cell tile][gene tile][1024] element offsets beyond 2^31, byte offsets beyond 2^32) on the matrix-core kernels; on top of
     the properties, Z_i and Z_j of the two layouts of the same matrix agree to 2e-6."""
     from oriana_amd import engine
     from oriana_amd.models import GaP
@@ -584,7 +584,7 @@ def test_config4_full_size_properties(dense_density):
     ct = engine.CountTiles.from_chunks(n, m, chunk, 8192, 'cuda', dense_density=dense_density)
     if dense_density:
         assert ct.gd >= 3000 and ct.gd % 32 == 0 and ct.dense is not None
-        assert ct.dense.x.numel() > 2 ** 32                   # element offsets of the dense block beyond 32 bits
+        assert ct.dense.x.numel() > 2 ** 31 and 2 * ct.dense.x.numel() > 2 ** 32     # element offsets beyond int32, byte offsets beyond 32 bits
     else:
         assert ct.gd == 0
         assert ct.rslots > 2 ** 31 and ct.cslots > 2 ** 31    # slot indices beyond int32, byte offsets beyond 2^34

@@ -288,8 +288,10 @@ def test_rccl_single_rank_rehearsal():
         out[tag] = json.loads(lines[0])
     d = out['rccl']
     assert d['exchange_rehearsal']['backend'] == 'nccl' and d['exchange_rehearsal']['ranks'] == 1
-    # 1 warm-up + 4 timed sweeps, each one exchange of two collectives (float64 partials, float32 per-gene sums)
-    assert d['exchange_rehearsal']['exchanges'] == 5 and d['exchange_rehearsal']['collectives'] == 10
+    # every sweep (1 warm-up + 4 timed + the un-instrumented loop of a launch-bound workload) is one exchange of two
+    # collectives (float64 partials started before the column pass, float32 per-gene sums after it)
+    assert d['exchange_rehearsal']['exchanges'] >= 5
+    assert d['exchange_rehearsal']['collectives'] == 2 * d['exchange_rehearsal']['exchanges']
     assert d['config']['collectives_per_sweep'] == 2
     assert 'exchange_rehearsal' not in out['plain']
     assert abs(d['check'] / out['plain']['check'] - 1.0) < 1e-6

@@ -257,6 +257,16 @@ int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, con
                        const int32_t *row_perm, const int32_t *col_perm, float *Z_hat_i, float *Z_hat_j, int64_t K,
                        void *stream);
 
+/* The same with the D_hat[i, k] weight of zigap.py:94 on the gene side: Z_hat_j[j, k] += dq[i, k] r_ijk (dq: (n, K) float32,
+ * caller's cell order; NULL = oriana_dense_fixup). */
+int oriana_dense_fixup_weighted(const oriana_dense *d, const int32_t *flag, float *S, const float *logU, const float *logV,
+                                const int32_t *row_perm, const int32_t *col_perm, float *Z_hat_i, float *Z_hat_j,
+                                const float *dq, int64_t K, void *stream);
+/* D_hat[i, j] = value at every non-zero count of the dense genes (zigap.py:77, 135); D_hat: (n, ld) float32, caller's
+ * cell / gene order. */
+int oriana_dense_fix_nz(const oriana_dense *d, float *D_hat, int64_t ld, const int32_t *row_perm, const int32_t *col_perm,
+                        double value, void *stream);
+
 /* Count statistics / deviance sums of the dense genes (the share of oriana_count_stats and oriana_metric_nnz that the
  * sliced layout of a hybrid matrix does not cover): colsum, colnnz (caller's gene order), out2 += {sum (x log x - x),
  * sum x^2}; with U, V (dense float64 (n, K), (m, K)): out4 += {sum Lambda, sum x log Lambda, sum Lambda^2,
@@ -446,6 +456,8 @@ int oriana_dense_t_times_factor_f32(double *out, const float *D, const double *W
 int64_t oriana_dense_t_scratch_floats(int64_t n, int64_t K);
 /* either output may be NULL */
 int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream);
+/* the same with an explicit leading dimension of p_d / D_hat (the sliced part of a hybrid layout: cm->m counts its own genes only) */
+int oriana_dropout_fix_nz_ld(const oriana_counts *cm, double *p_d, float *D_hat, double value, int64_t ld, void *stream);
 int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream);
 /* the same for a float32 matrix (D_hat, while p_d == D_hat exactly: zigap.py:77) */
 int oriana_colsum_wide_f32(double *out, const float *A, int64_t rows, int64_t m, void *stream);

@@ -63,6 +63,8 @@ _SIGS = {
     'oriana_dense_col_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _I, _I, _P]),
     'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_dense_metric': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_dense_fixup_weighted': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_dense_fix_nz': (c_int, [ctypes.POINTER(OrianaDense), _P, _I, _P, _P, c_double, _P]),
     'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),
     'oriana_finalize_slabs': (c_int, [_P, _P, _P, _I, _P, _I, _I, _P]),
     'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -90,6 +92,7 @@ _SIGS = {
     'oriana_dropout_metric': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'oriana_nzmask_f32': (c_int, [_P, _P, _I, _I, _P]),
     'oriana_dropout_fix_nz': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, c_double, _P]),
+    'oriana_dropout_fix_nz_ld': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, c_double, _I, _P]),
     'oriana_mul_f64_f32': (c_int, [_P, _P, _P, _I, _P]),
     'oriana_colsum_wide_f64': (c_int, [_P, _P, _I, _I, _P]),
     'oriana_colsum_wide_f32': (c_int, [_P, _P, _I, _I, _P]),

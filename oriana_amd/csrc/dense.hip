@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_nzmask(uint32_t *__restrict__ mask, con
 
 // p_d[X != 0] = 1 - 1e-10 (zigap.py:135): one thread per row-side slot of the tiled layout.
 __global__ __launch_bounds__(256) void k_dropout_fix_nz(oriana_counts cm, double *__restrict__ p_d,
-                                                        float *__restrict__ D_hat, double one) {
+                                                        float *__restrict__ D_hat, double one, int64_t ld) {
     const int64_t t = blockIdx.x;
     const int64_t rb = t / cm.ncb, cb = t - rb * cm.ncb;
     const int64_t rbase = cm.roff[t];
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void k_dropout_fix_nz(oriana_counts cm, double
             const int64_t jp = cb * TILE + rec.col;
             const int64_t i = cm.row_perm ? (int64_t)cm.row_perm[ip] : ip;
             const int64_t j = cm.col_perm ? (int64_t)cm.col_perm[jp] : jp;
-            if (p_d) p_d[i * cm.m + j] = one;
-            if (D_hat) D_hat[i * cm.m + j] = (float)one;
+            if (p_d) p_d[i * ld + j] = one;
+            if (D_hat) D_hat[i * ld + j] = (float)one;
         }
     }
 }
@@ -284,13 +284,18 @@ extern "C" int oriana_nzmask_f32(uint32_t *mask, const float *D, int64_t rows, i
     return 0;
 }
 
-extern "C" int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream) {
-    if (!cm || (!p_d && !D_hat)) return ORIANA_EINVAL;
+extern "C" int oriana_dropout_fix_nz_ld(const oriana_counts *cm, double *p_d, float *D_hat, double value, int64_t ld,
+                                        void *stream) {
+    if (!cm || (!p_d && !D_hat) || ld < cm->m) return ORIANA_EINVAL;
     const int64_t nt = cm->nrb * cm->ncb;
     if (nt == 0 || cm->rslots == 0) return 0;
-    hipLaunchKernelGGL(k_dropout_fix_nz, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, p_d, D_hat, value);
+    hipLaunchKernelGGL(k_dropout_fix_nz, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, p_d, D_hat, value, ld);
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_dropout_fix_nz(const oriana_counts *cm, double *p_d, float *D_hat, double value, void *stream) {
+    return cm ? oriana_dropout_fix_nz_ld(cm, p_d, D_hat, value, cm->m, stream) : ORIANA_EINVAL;
 }
 
 extern "C" int oriana_colsum_wide_f64(double *out, const double *A, int64_t rows, int64_t m, void *stream) {

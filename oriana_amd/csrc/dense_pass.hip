@@ -581,7 +581,8 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
                                                   const int32_t *__restrict__ flag, const float *__restrict__ logU,
                                                   const float *__restrict__ logV, const int32_t *__restrict__ row_perm,
                                                   const int32_t *__restrict__ col_perm, float *__restrict__ Zi,
-                                                  float *__restrict__ Zj, int64_t n, int ngt, int K) {
+                                                  float *__restrict__ Zj, int64_t n, int ngt, int K,
+                                                  const float *__restrict__ dq) {
     __shared__ int nhit;
     __shared__ int hits[256];
     const int64_t ct = blockIdx.x;
@@ -619,11 +620,29 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
                 const float expectation = (x * expf(lu[k] + lv[k])) / den;            // gap.py:78
                 if (expectation != 0.f) {
                     atomicAdd(&Zi[i * K + k], expectation);
-                    atomicAdd(&Zj[j * K + k], expectation);
+                    atomicAdd(&Zj[j * K + k], dq ? dq[i * K + k] * expectation : expectation);   // zigap.py:94 (D_hat[i, k])
                 }
             }
         }
         __syncthreads();
+    }
+}
+
+// D_hat[i, j] = value at every non-zero count of the dense block (zigap.py:77, 135): one work-group per (cell tile, gene tile)
+__global__ __launch_bounds__(256) void k_dn_fix_nz(const uint16_t *__restrict__ Xd, float *__restrict__ D_hat, int64_t ld,
+                                                   const int32_t *__restrict__ row_perm, const int32_t *__restrict__ col_perm,
+                                                   float value, int64_t n, int ngt) {
+    const int gt = blockIdx.x;
+    const int64_t ct = blockIdx.y;
+    const uint16_t *blk = Xd + (ct * ngt + gt) * 1024;
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        if (blk[e] == 0) continue;
+        const int v = ((e >> 9) << 3) | (e & 7), l = (e >> 3) & 63;
+        const int64_t ip = ct * 32 + (l & 31), jp = (int64_t)gt * 32 + acc_row(v, l >> 5);
+        if (ip >= n) continue;
+        const int64_t i = row_perm ? (int64_t)row_perm[ip] : ip;
+        const int64_t j = col_perm ? (int64_t)col_perm[jp] : jp;
+        D_hat[i * ld + j] = value;
     }
 }
 
@@ -852,15 +871,33 @@ extern "C" int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, co
     return 0;
 }
 
-extern "C" int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
-                                  const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
-                                  float *Zj, int64_t K, void *stream) {
+extern "C" int oriana_dense_fixup_weighted(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
+                                           const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
+                                           float *Zj, const float *dq, int64_t K, void *stream) {
     if (!dense_ok(d) || K <= 0) return ORIANA_EINVAL;
     if (d->gd == 0 || d->n == 0) return 0;
     if (!flag || !S || !logU || !logV || !Zi || !Zj) return ORIANA_EINVAL;
     const int ngt = (int)(d->gd / 32);
     hipLaunchKernelGGL(k_dn_fixup, dim3((unsigned)d->nct), dim3(256), 0, (hipStream_t)stream, d->x, S,
-                       flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K);
+                       flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K, dq);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
+                                  const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
+                                  float *Zj, int64_t K, void *stream) {
+    return oriana_dense_fixup_weighted(d, flag, S, logU, logV, row_perm, col_perm, Zi, Zj, nullptr, K, stream);
+}
+
+extern "C" int oriana_dense_fix_nz(const oriana_dense *d, float *D_hat, int64_t ld, const int32_t *row_perm,
+                                   const int32_t *col_perm, double value, void *stream) {
+    if (!dense_ok(d) || ld < d->gd) return ORIANA_EINVAL;
+    if (d->gd == 0 || d->n == 0) return 0;
+    if (!D_hat) return ORIANA_EINVAL;
+    const int ngt = (int)(d->gd / 32);
+    hipLaunchKernelGGL(k_dn_fix_nz, dim3((unsigned)ngt, (unsigned)((d->n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, d->x,
+                       D_hat, ld, row_perm, col_perm, (float)value, d->n, ngt);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

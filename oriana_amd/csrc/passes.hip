@@ -2643,7 +2643,8 @@ extern "C" int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag, f
     if (nt == 0 || cm->nnz == 0) return 0;
     if (!tile_flag || !s_cs || !logU || !logV) return ORIANA_EINVAL;
     const int quirk = (variant & 4) ? 1 : 0;
-    if (quirk && (!dq || K > cm->m)) return ORIANA_EQUIRK;
+    // (K <= number of genes is the caller's to check: cm->m of the sliced part of a hybrid layout counts its own genes only)
+    if (quirk && !dq) return ORIANA_EQUIRK;
     hipLaunchKernelGGL(k_fixup, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, tile_flag, s_cs,
                        sw_cs, s_rs, logU, logV, S_tilde, S_hat, w_nz, dq, Zi, Zj, Zlog, (int)K, quirk);
     ORIANA_LAUNCH_CHECK();

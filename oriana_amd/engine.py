@@ -755,6 +755,11 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
     n, m = ct.n, ct.m
     sparse = S_hat is not None
     st = stream_ptr()
+    if ct.dense is not None:
+        if sparse or w_nz is not None or Z_log is not None:
+            raise _lib.OrianaHipError('the hybrid (dense-gene) layout serves the pCMF and ZI-pCMF nests (no masks, no per-entry '
+                                      'weights, no log sums): pack without dense_density for this use')
+        return _zq_hybrid(ws, Z_i, Z_j, log_U_hat, log_V_hat, dq, phase)
     if phase in ('all', 'rows'):
         _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
         if w_nz is not None and ws.sw_cs is None:
@@ -831,6 +836,56 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             with _span(ws, 'col_pass_log'):
                 col_pass(ct, s_log, G2, C2, K)
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ws.center_ptr, ptr(ct.col_perm), m, K, st)
+
+
+def _zq_hybrid(ws, Z_i, Z_j, log_U_hat, log_V_hat, dq, phase):
+    """zigap.py:79-95 inside the models (D_hat = 1 at every non-zero count) on a HYBRID layout: the pCMF nest of zq_gap with
+    the D_hat[i, k] weight of zigap.py:94 (`dq`, kept under reference_quirks) on the gene side -- the column pass and the
+    dense gene-side kernel then run against FU * dq instead of FU, the two slow paths weight their additions to Z_j."""
+    ct, K = ws.ct, ws.K
+    n, m, gd, dn = ct.n, ct.m, ct.gd, ct.dense
+    st = stream_ptr()
+    FVs, Cs = ptr(ws.FV) + 4 * gd * ws.Kp, ptr(ws.C) + 4 * gd * ws.Kp
+    if phase in ('all', 'rows'):
+        _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
+        if dq is not None:
+            _check_f32(dq, (n, K))
+        gs = ws.row_gene_splits
+        zero_R = ws.R if ct.ms == 0 else None
+        factor_prep_pair(ws, log_U_hat, log_V_hat, clear=(Z_i, Z_j, ws.C, ws.tile_flag, zero_R))
+        if ct.ms > 0:
+            with _span(ws, 'row_pass'):
+                if gs > 1:
+                    call('oriana_row_pass_split', ct.sparse_struct, ptr(ws.FU), FVs, ptr(ws.R), ptr(ws.s_cs), ptr(ws.tile_flag), K, gs, st)
+                else:
+                    call('oriana_row_pass', ct.sparse_struct, ptr(ws.FU), FVs, None, ptr(ws.R), ptr(ws.s_cs), None, None,
+                         ptr(ws.tile_flag), K, st)
+        with _span(ws, 'dense_images'):
+            call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
+        with _span(ws, 'dense_row'):
+            call('oriana_dense_row_pass', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S), ptr(ws.dn_flag), K,
+                 ws.dn_gene_splits, st)
+        with _span(ws, 'fixup'):
+            if ct.ms > 0:
+                call('oriana_fixup', ct.sparse_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat), ptr(log_V_hat),
+                     None, None, None, ptr(dq), ptr(Z_i), ptr(Z_j), None, K, 4 if dq is not None else 0, st)
+            call('oriana_dense_fixup_weighted', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
+                 ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(dq), K, st)
+        call('oriana_finalize_slabs', ptr(Z_i), ptr(ws.FU), ptr(ws.R), gs, ptr(ct.row_perm), n, K, st)
+    if phase == 'rows':
+        return
+    G = ws.FU
+    if dq is not None:
+        G = ws.extra('GQ', n)
+        call('oriana_scale_factor', ptr(G), ptr(ws.FU), ptr(dq), ptr(ct.row_perm), n, K, 0, st)
+    if ct.ms > 0:
+        with _span(ws, 'col_pass'):
+            col_pass(ct, ws.s_cs, G, ws.C, K, C_ptr=Cs)
+    with _span(ws, 'dense_images'):
+        call('oriana_dense_images', ptr(ws.dn_imgU), ptr(G), n, K, 1, st)
+    with _span(ws, 'dense_col'):
+        call('oriana_dense_col_pass', dn.c_struct, ptr(ws.dn_imgU), ptr(ws.dn_S), ptr(ws.C), K, ws.dn_cell_splits, st)
+    call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
 
 
 def _stateless_ws(n, m, K, X):

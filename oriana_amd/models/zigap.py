@@ -37,7 +37,10 @@ class _ZIMixin:
         # p_d = (X > 0) as float (zigap.py:77): exactly 1.0 at the non-zero counts, so D_hat holds it
         # exactly and the float64 matrix is only evaluated on access (LazyParameter)
         self._D_hat = torch.zeros(n, m, dtype=torch.float32, device=dev)
-        call('oriana_dropout_fix_nz', self.counts.c_struct, None, ptr(self._D_hat), 1.0, stream_ptr())
+        ct = self.counts
+        call('oriana_dropout_fix_nz_ld', ct.sparse_struct, None, ptr(self._D_hat), 1.0, m, stream_ptr())
+        if ct.dense is not None:           # hybrid layout: the non-zero counts of the dense genes
+            call('oriana_dense_fix_nz', ct.dense.c_struct, ptr(self._D_hat), m, ptr(ct.row_perm), ptr(ct.col_perm), 1.0, stream_ptr())
         self.p_d = LazyParameter((n, m), dev, lambda: self._D_hat.double())
         self._pd_sum = torch.zeros(m, dtype=torch.float64, device=dev)
         # bit mask of X != 0 (constant): lets the D update apply p_d[X != 0] = 1 - 1e-10 in its own pass

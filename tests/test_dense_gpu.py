@@ -145,3 +145,33 @@ def test_hybrid_equals_sliced_layout(eng):
     assert out[0][2] == 0 and out[1][2] >= 32
     assert err_colrel(out[1][0], out[0][0]) < 2e-6
     assert err_colrel(out[1][1], out[0][1]) < 2e-6
+
+
+@pytest.mark.parametrize('n,m,K,quirk', [(257, 131, 7, True), (300, 200, 50, True), (400, 160, 100, True), (300, 200, 64, False)])
+def test_zq_zigap_hybrid_vs_oracle(eng, n, m, K, quirk):
+    """zigap.py:79-95 as the model runs it (D_hat = 1 at the non-zero counts, the D_hat[i, k] index of zigap.py:94 under
+    reference_quirks) through the hybrid layout against the C oracle; also with a cell on the exact slow path."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(n + 13 * m + K)
+    dens = np.clip(rng.beta(1.0, 2.0, size=m), 0.01, 1.0)
+    dens[:40] = np.linspace(1.0, 0.4, 40)
+    X = _counts(rng, n, m, dens).astype(np.float32)
+    lu = (rng.normal(size=(n, K)) * 1.5).astype(np.float32)
+    lv = (rng.normal(size=(m, K)) * 1.5 - 1.0).astype(np.float32)
+    lu[3] -= 80.0
+    D = rng.random((n, m)).astype(np.float32)
+    D[X != 0] = 1.0                                   # zigap.py:135 + bernoulli.py:45
+    ct = eng.CountTiles.from_dense(X, 'cuda', dense_density=0.3)
+    assert ct.gd >= 32
+    ws = eng.ZWorkspace(ct, K)
+    Zi = torch.empty(n, K, device='cuda'); Zj = torch.empty(m, K, device='cuda')
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    dq = c(D[:, :K]) if quirk else None
+    eng.zq(ws, Zi, Zj, None, c(lu), c(lv), dq=dq)
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_zigap(r[0], r[1], r[2], lu, lv, D, X, quirk=quirk)
+    assert int(ws.dn_flag.sum().item()) > 0
+    assert err_colrel(Zi.cpu().numpy(), r[0]) < RTOL
+    assert err_colrel(Zj.cpu().numpy(), r[1]) < RTOL
+    with pytest.raises(Exception):                   # the sparse nests stay on the sliced layout
+        eng.zq(ws, Zi, Zj, None, c(lu), c(lv), S_tilde=c(np.ones((m, K), np.float32)), S_hat=c(np.ones((m, K), np.float32)))

@@ -72,11 +72,12 @@ def test_single_sweeps(path):
         assert_state_close(M.state(), state_of(g, b), what='%s->%s' % (a, b), exact=exact)
 
 
-@pytest.mark.parametrize('path', golden_files('gap_*.npz'), ids=os.path.basename)
+@pytest.mark.parametrize('path', golden_files('gap_*.npz') + golden_files('zigap_*.npz'), ids=os.path.basename)
 def test_single_sweeps_hybrid_layout(path):
-    """The pCMF goldens through the HYBRID layout at model level: every gene expressed in >= 10 % of the cells on the
-    matrix-core kernels (csrc/dense_pass.hip), the rest on the sliced layout -- each sweep from the reference's own
-    state lands on the reference's next state within 1e-5, with the 1e-15 clamp patterns identical.  ('auto' keeps a
+    """The pCMF and ZI-pCMF goldens through the HYBRID layout at model level: every gene expressed in >= 10 % of the cells
+    on the matrix-core kernels (csrc/dense_pass.hip), the rest on the sliced layout -- each sweep from the reference's own
+    state lands on the reference's next state within 1e-5, with the 1e-15 clamp patterns (and the 1 - 1e-10 mask of p_d)
+    identical.  ZI-pCMF: the D_hat[i, k] weight of zigap.py:94 rides on the gene-side factor image.  ('auto' keeps a
     matrix below 2e8 entries on the sliced layout, so the other golden tests never take this route.)"""
     g = load_golden(path)
     M = _make(g, dense_density=0.1)

@@ -46,6 +46,7 @@ WORKLOADS = {
     'c4_eighth': ('GaP', 125000, 30000, 100, 0.10, 'one rank\'s share of configs[3] at 8 GPUs'),
     'c4_eighth_z05': ('GaP', 125000, 30000, 100, 0.50, 'the same share at the reference generator\'s default z'),
     'c3_zi_z05': ('ZIGaP', 100000, 20000, 50, 0.50, 'configs[2] at the reference generator\'s default z'),
+    'c5_sparse_z05': ('SparseGaP', 500000, 25000, 64, 0.50, 'configs[4] at the reference generator\'s default z'),
 }
 MODEL_LABEL = {'GaP': 'pCMF', 'ZIGaP': 'ZI-pCMF', 'SparseGaP': 'sparse pCMF'}
 
@@ -218,7 +219,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     dd = None
     if mname == 'GaP' and engine.dense_supported(K):
         dd = engine.auto_dense_density(n_total, m, K) if args.dense_density == 'auto' else (float(args.dense_density) or None)
-    elif mname == 'ZIGaP' and engine.dense_supported(K) and args.dense_density != 'auto':
+    elif mname in ('ZIGaP', 'SparseGaP') and engine.dense_supported(K) and args.dense_density != 'auto':
         dd = float(args.dense_density) or None        # (ZI-pCMF: the hybrid layout on request only)
     counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
                                            reduce_fn=(lambda t: odist.all_reduce_sum(t)) if (world > 1 or odist.sharded()) else None,

@@ -37,9 +37,12 @@ namespace dn {
 #define DN_STAMP(K) do { } while (0)
 #endif
 
-// One work-group per tile of 32 factor rows (genes or cells); F is a padded (rows, Kp) float32 factor matrix.
+// One work-group per tile of 32 factor rows (genes or cells); F is a padded (rows, Kp) float32 factor matrix.  F2: the
+// matrix the SECOND image (the B operand of the accumulation, and its tail pieces) is taken from -- the sparse models
+// accumulate R against FV * S_hat while den runs against the masked FV (sparse_gap.py:88-95); F2 = F otherwise.
 template <int KC, int TAIL, bool BOTH>
-__global__ __launch_bounds__(512) void k_dn_images(u4v *__restrict__ img, const float *__restrict__ F, int64_t rows, int Kp) {
+__global__ __launch_bounds__(512) void k_dn_images(u4v *__restrict__ img, const float *__restrict__ F,
+                                                   const float *__restrict__ F2, int64_t rows, int Kp) {
     using C = Cfg<KC, TAIL>;
     constexpr int PIMG = BOTH ? C::PV : C::PU;
     const int tid = threadIdx.x;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(512) void k_dn_images(u4v *__restrict__ img, const 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int64_t r = r0 + acc_row(8 * q + e, hh);
-                x[e] = (r < rows && kk < C::KM) ? F[r * Kp + kk] : 0.f;
+                x[e] = (r < rows && kk < C::KM) ? F2[r * Kp + kk] : 0.f;
             }
             u4v o[3];
             split8(x, o);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(512) void k_dn_images(u4v *__restrict__ img, const 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int64_t r = r0 + acc_row(4 * q + e, hh);
-                t[e] = (r < rows) ? F[r * Kp + C::KM + j] : 0.f;
+                t[e] = (r < rows) ? F2[r * Kp + C::KM + j] : 0.f;
             }
         }
         dst0[(BOTH ? C::P1 : 0) + C::P2 + tid] = __builtin_bit_cast(u4v, t);
@@ -582,7 +585,8 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
                                                   const float *__restrict__ logV, const int32_t *__restrict__ row_perm,
                                                   const int32_t *__restrict__ col_perm, float *__restrict__ Zi,
                                                   float *__restrict__ Zj, int64_t n, int ngt, int K,
-                                                  const float *__restrict__ dq) {
+                                                  const float *__restrict__ dq, const float *__restrict__ S_tilde,
+                                                  const float *__restrict__ S_hat, float *__restrict__ Zlog) {
     __shared__ int nhit;
     __shared__ int hits[256];
     const int64_t ct = blockIdx.x;
@@ -612,15 +616,28 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
             const int64_t i = row_perm ? (int64_t)row_perm[ip] : ip;
             const int64_t j = col_perm ? (int64_t)col_perm[jp] : jp;
             const float *lu = logU + i * K, *lv = logV + j * K;
+            const float *st = S_tilde ? S_tilde + j * K : nullptr;
+            const float *sh = S_hat ? S_hat + j * K : nullptr;
             const float x = (float)xi;
             float den = 0.f;
-            for (int k = 0; k < K; ++k) den += expf(lu[k] + lv[k]);
+            for (int k = 0; k < K; ++k) {
+                float ex = expf(lu[k] + lv[k]);
+                if (st) ex *= st[k];                                                    // sparse_gap.py:88
+                den += ex;
+            }
             den = (den > 0.f) ? den : 1.0f;
             for (int k = 0; k < K; ++k) {
-                const float expectation = (x * expf(lu[k] + lv[k])) / den;            // gap.py:78
-                if (expectation != 0.f) {
-                    atomicAdd(&Zi[i * K + k], expectation);
-                    atomicAdd(&Zj[j * K + k], dq ? dq[i * K + k] * expectation : expectation);   // zigap.py:94 (D_hat[i, k])
+                const float ls = lu[k] + lv[k];
+                float ex = expf(ls);
+                if (st) ex *= st[k];
+                const float expectation = (x * ex) / den;                               // gap.py:78
+                const float vi = sh ? sh[k] * expectation : expectation;               // sparse_gap.py:95
+                if (vi != 0.f) atomicAdd(&Zi[i * K + k], vi);
+                const float vj = dq ? dq[i * K + k] * expectation : expectation;        // zigap.py:94 (D_hat[i, k])
+                if (vj != 0.f) atomicAdd(&Zj[j * K + k], vj);
+                if (Zlog) {
+                    const float vl = expectation * ls;                                  // zigap.py:95 / sparse_gap.py:97
+                    if (vl != 0.f) atomicAdd(&Zlog[j * K + k], vl);
                 }
             }
         }
@@ -795,23 +812,29 @@ extern "C" int oriana_dense_pack(const void *X, int xdtype, int64_t rows, int64_
     return 0;
 }
 
-extern "C" int oriana_dense_images(void *img, const float *F, int64_t rows, int64_t K, int side, void *stream) {
+extern "C" int oriana_dense_images2(void *img, const float *F, const float *F2, int64_t rows, int64_t K, int side,
+                                    void *stream) {
     int kc, tl, kp;
     if (rows < 0 || K <= 0) return ORIANA_EINVAL;
     if (!dn_cfg(K, &kc, &tl, &kp)) return ORIANA_EKRANGE;
     if (rows == 0) return 0;
     if (!img || !F) return ORIANA_EINVAL;
+    if (!F2) F2 = F;
     const unsigned tiles = (unsigned)((rows + 31) / 32);
     hipStream_t s = (hipStream_t)stream;
 #define ORIANA_DN_CALL(KC, TL)                                                                                              \
     do {                                                                                                                    \
-        if (side) hipLaunchKernelGGL((k_dn_images<KC, TL, false>), dim3(tiles), dim3(512), 0, s, (u4v *)img, F, rows, kp);  \
-        else hipLaunchKernelGGL((k_dn_images<KC, TL, true>), dim3(tiles), dim3(512), 0, s, (u4v *)img, F, rows, kp);        \
+        if (side) hipLaunchKernelGGL((k_dn_images<KC, TL, false>), dim3(tiles), dim3(512), 0, s, (u4v *)img, F, F2, rows, kp); \
+        else hipLaunchKernelGGL((k_dn_images<KC, TL, true>), dim3(tiles), dim3(512), 0, s, (u4v *)img, F, F2, rows, kp);     \
     } while (0)
     ORIANA_DN_FOR_CFG(kc, tl, ORIANA_DN_CALL);
 #undef ORIANA_DN_CALL
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_dense_images(void *img, const float *F, int64_t rows, int64_t K, int side, void *stream) {
+    return oriana_dense_images2(img, F, F, rows, K, side, stream);
 }
 
 extern "C" int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
@@ -871,17 +894,24 @@ extern "C" int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, co
     return 0;
 }
 
+extern "C" int oriana_dense_fixup_variant(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
+                                          const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
+                                          float *Zj, float *Zlog, const float *dq, const float *S_tilde, const float *S_hat,
+                                          int64_t K, void *stream) {
+    if (!dense_ok(d) || K <= 0) return ORIANA_EINVAL;
+    if (d->gd == 0 || d->n == 0) return 0;
+    if (!flag || !S || !logU || !logV || !Zi || !Zj || ((S_tilde == nullptr) != (S_hat == nullptr))) return ORIANA_EINVAL;
+    const int ngt = (int)(d->gd / 32);
+    hipLaunchKernelGGL(k_dn_fixup, dim3((unsigned)d->nct), dim3(256), 0, (hipStream_t)stream, d->x, S,
+                       flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K, dq, S_tilde, S_hat, Zlog);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int oriana_dense_fixup_weighted(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
                                            const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
                                            float *Zj, const float *dq, int64_t K, void *stream) {
-    if (!dense_ok(d) || K <= 0) return ORIANA_EINVAL;
-    if (d->gd == 0 || d->n == 0) return 0;
-    if (!flag || !S || !logU || !logV || !Zi || !Zj) return ORIANA_EINVAL;
-    const int ngt = (int)(d->gd / 32);
-    hipLaunchKernelGGL(k_dn_fixup, dim3((unsigned)d->nct), dim3(256), 0, (hipStream_t)stream, d->x, S,
-                       flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K, dq);
-    ORIANA_LAUNCH_CHECK();
-    return 0;
+    return oriana_dense_fixup_variant(d, flag, S, logU, logV, row_perm, col_perm, Zi, Zj, nullptr, dq, nullptr, nullptr, K, stream);
 }
 
 extern "C" int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,

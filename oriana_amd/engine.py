@@ -649,16 +649,17 @@ def col_pass(ct, s_cs, G, C, K, C_ptr=None):
     call('oriana_col_pass', ct.sparse_struct, ptr(s_cs), ptr(G), Cp, K, ptr(w), 0 if w is None else w.shape[0], stream_ptr())
 
 
-def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K):
+def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K, goff=0):
     """C1 += s G1 and C2 += s G2 from one walk over the column-side stream (oriana_col_pass_dual).  Returns False when
-    the two factor images do not fit in LDS (or in the deterministic debug mode): the caller runs two column passes."""
+    the two factor images do not fit in LDS (or in the deterministic debug mode): the caller runs two column passes.
+    `goff`: byte offset of the sliced part's first gene row inside C1 / C2 (hybrid layouts)."""
     if DETERMINISTIC or not _FUSE_SPARSE_COLS:
         return False
     w = ct.col_work_width(1)
     if w is None:
         return False
-    rc = _lib.load().oriana_col_pass_dual(ct.c_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1), ptr(C2), K, ptr(w), w.shape[0],
-                                          stream_ptr())
+    rc = _lib.load().oriana_col_pass_dual(ct.sparse_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1) + goff, ptr(C2) + goff, K, ptr(w),
+                                          w.shape[0], stream_ptr())
     if rc not in (0, -2):
         raise _lib.OrianaHipError('oriana_col_pass_dual failed with code %d' % rc)
     return rc == 0
@@ -750,53 +751,70 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
       Z_log[j,k] = sum_i r_ijk (lu_ik + lv_jk)                 (zigap.py:95) -- skipped when Z_log is None
     with r_ijk = x_ij e_k / sum_k e_k, e_k = exp(lu_ik + lv_jk) [S_tilde[j,k]].  Outputs first,
     zero-filled here, float32 device tensors.  `phase` as in zq_gap ('rows': everything Z_i needs; 'cols': the
-    per-gene sums; both phases must get the same arguments)."""
+    per-gene sums; both phases must get the same arguments).
+    HYBRID layouts (every nest without per-entry weights): the sliced kernels cover the packed genes [gd, m) -- their
+    gene-side pointers start gd rows in --, the dense-gene kernels the first gd: den against the (masked) FV image, the
+    accumulation against FV * S_hat (oriana_dense_images2), one gene-side pass per per-gene sum (FU [* dq], and the
+    centred E[log U]-weighted factor of the log sums)."""
     ct, K = ws.ct, ws.K
     n, m = ct.n, ct.m
     sparse = S_hat is not None
     st = stream_ptr()
-    if ct.dense is not None:
-        if sparse or w_nz is not None or Z_log is not None:
-            raise _lib.OrianaHipError('the hybrid (dense-gene) layout serves the pCMF and ZI-pCMF nests (no masks, no per-entry '
-                                      'weights, no log sums): pack without dense_density for this use')
-        return _zq_hybrid(ws, Z_i, Z_j, log_U_hat, log_V_hat, dq, phase)
+    dn, gd = ct.dense, ct.gd
+    if dn is not None and w_nz is not None:
+        raise _lib.OrianaHipError('a hybrid (dense-gene) layout carries no per-entry weights: pack without dense_density for this use')
+    cst = ct.sparse_struct                       # (== the whole layout when there are no dense genes)
+    goff = 4 * gd * ws.Kp                        # byte offset of the sliced part's first gene row in FV, C, ...
+    have_sliced = ct.ms > 0 or dn is None
     if phase in ('all', 'rows'):
         _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
         if w_nz is not None and ws.sw_cs is None:
             ws.sw_cs = torch.zeros(max(ct.cslots, 1), dtype=torch.float32, device=ct.device)
     sw_cs = ws.sw_cs if w_nz is not None else None
     if phase in ('all', 'rows'):
-        factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=S_tilde, clear=(Z_i, Z_j, ws.C, ws.tile_flag, Z_log))
+        zero_R = ws.R if not have_sliced else None          # (no sliced part: the dense row pass adds into it)
+        factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=S_tilde, clear=(Z_i, Z_j, ws.C, ws.tile_flag, Z_log, zero_R))
         # sparse models: the S_hat-weighted row sums (sparse_gap.py:95).  Where two factor images fit in LDS (Kp <= 64)
         # they come out of the row pass itself (dot product against FV, accumulation against FV * S_hat); otherwise the
         # pass leaves s in row-side slots and a second row product follows.
         fused = False
+        F2 = None
         if sparse:
             F2 = ws.extra('FVS', m)
             call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
-            if _FUSE_SPARSE_ROWS:
+        if have_sliced:
+            if sparse and _FUSE_SPARSE_ROWS:
                 with _span(ws, 'row_pass'):
-                    rc = _lib.load().oriana_row_pass_masked(ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(F2), ptr(w_nz), ptr(ws.R),
+                    rc = _lib.load().oriana_row_pass_masked(cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(F2) + goff, ptr(w_nz), ptr(ws.R),
                                                             ptr(ws.s_cs), ptr(sw_cs), ptr(ws.tile_flag), K, st)
                 if rc not in (0, -2):
                     raise _lib.OrianaHipError('oriana_row_pass_masked failed with code %d' % rc)
                 fused = rc == 0
-        if not fused:
-            if sparse and ws.s_rs is None:       # row-side copy of s for the second row product (lazy: the fused form never needs it)
-                ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
-            with _span(ws, 'row_pass'):
-                call('oriana_row_pass', ct.c_struct, ptr(ws.FU), ptr(ws.FV), ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
-                     ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
-        with _span(ws, 'fixup'):
-            call('oriana_fixup', ct.c_struct, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs),
-                 ptr(ws.s_rs) if (sparse and not fused) else None,
-                 ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
-                 K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
-        R = ws.R
-        if sparse and not fused:
-            with _span(ws, 'row_spmm'):
-                call('oriana_row_spmm', ct.c_struct, ptr(ws.s_rs), ptr(w_nz), ptr(F2), ptr(ws.R), K, st)
-        call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(R), None, ptr(ct.row_perm), n, K, 1, st)
+            if not fused:
+                if sparse and ws.s_rs is None:   # row-side copy of s for the second row product (lazy: the fused form never needs it)
+                    ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
+                with _span(ws, 'row_pass'):
+                    call('oriana_row_pass', cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
+                         ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
+            with _span(ws, 'fixup'):
+                call('oriana_fixup', cst, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs),
+                     ptr(ws.s_rs) if (sparse and not fused) else None,
+                     ptr(log_U_hat), ptr(log_V_hat), ptr(S_tilde), ptr(S_hat), ptr(w_nz), ptr(dq), ptr(Z_i), ptr(Z_j), ptr(Z_log),
+                     K, (1 if sparse else 0) | (2 if w_nz is not None else 0) | (4 if dq is not None else 0), st)
+            if sparse and not fused:
+                with _span(ws, 'row_spmm'):
+                    call('oriana_row_spmm', cst, ptr(ws.s_rs), ptr(w_nz), ptr(F2) + goff, ptr(ws.R), K, st)
+        if dn is not None:
+            # (after the sliced kernels: the dense row kernel ADDS its sums into R)
+            with _span(ws, 'dense_images'):
+                call('oriana_dense_images2', ptr(ws.dn_imgV), ptr(ws.FV), ptr(F2), gd, K, 0, st)
+            with _span(ws, 'dense_row'):
+                call('oriana_dense_row_pass', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S), ptr(ws.dn_flag), K,
+                     ws.dn_gene_splits, st)
+            with _span(ws, 'fixup'):
+                call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
+                     ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, st)
+        call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), n, K, 1, st)
         if Z_log is not None:
             # E[log U]-weighted row factor of the log sums: built NOW, from the pre-update E[log U] (the caller
             # may run the cell-side update between the two phases)
@@ -804,6 +822,13 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             call('oriana_scale_factor_centered', ptr(ws.extra('GL', n)), ptr(ws.FU), ptr(log_U_hat), ws.center_ptr, ptr(ct.row_perm), n, K, st)
     if phase == 'rows':
         return
+
+    def dense_cols(Gmat, Cmat):
+        """The dense genes' share of  Cmat += s Gmat  (gene-side kernel over the cell images of Gmat)."""
+        with _span(ws, 'dense_images'):
+            call('oriana_dense_images', ptr(ws.dn_imgU), ptr(Gmat), n, K, 1, st)
+        with _span(ws, 'dense_col'):
+            call('oriana_dense_col_pass', dn.c_struct, ptr(ws.dn_imgU), ptr(ws.dn_S), ptr(Cmat), K, ws.dn_cell_splits, st)
     # per-gene sums: weighted by D_hat[i, j] (sw), or -- zigap.py:94 -- by D_hat[i, k] on the plain s
     G, s_for_j = ws.FU, (sw_cs if sw_cs is not None else ws.s_cs)
     if dq is not None:
@@ -818,74 +843,31 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         G2 = ws.extra('GL', n)
         C2 = ws.extra('C2', m)
         C2.zero_()
-        if dq is None:                          # the per-gene sums and the log sums share factor and stream
+        if dq is None and have_sliced:          # the per-gene sums and the log sums share factor and stream
             with _span(ws, 'col_pass'):
-                dual_done = col_pass_dual(ct, s_log, ws.FU, G2, ws.C, C2, K)
-    if not dual_done:
+                dual_done = col_pass_dual(ct, s_log, ws.FU, G2, ws.C, C2, K, goff=goff)
+    if not dual_done and have_sliced:
         with _span(ws, 'col_pass'):
-            col_pass(ct, s_for_j, G, ws.C, K)
+            col_pass(ct, s_for_j, G, ws.C, K, C_ptr=ptr(ws.C) + goff)
+    if dn is not None:
+        dense_cols(G, ws.C)
     call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
     if Z_log is not None:
         if dq is not None:                      # the log sums use the D_hat[i, j]-weighted column sums
             ws.C.zero_()
+            if have_sliced:
+                with _span(ws, 'col_pass_log'):
+                    dual_done = col_pass_dual(ct, s_log, ws.FU, G2, ws.C, C2, K, goff=goff)
+                    if not dual_done:
+                        col_pass(ct, s_log, ws.FU, ws.C, K, C_ptr=ptr(ws.C) + goff)
+            if dn is not None:
+                dense_cols(ws.FU, ws.C)
+        if not dual_done and have_sliced:
             with _span(ws, 'col_pass_log'):
-                dual_done = col_pass_dual(ct, s_log, ws.FU, G2, ws.C, C2, K)
-                if not dual_done:
-                    col_pass(ct, s_log, ws.FU, ws.C, K)
-        if not dual_done:
-            with _span(ws, 'col_pass_log'):
-                col_pass(ct, s_log, G2, C2, K)
+                col_pass(ct, s_log, G2, C2, K, C_ptr=ptr(C2) + goff)
+        if dn is not None:
+            dense_cols(G2, C2)
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ws.center_ptr, ptr(ct.col_perm), m, K, st)
-
-
-def _zq_hybrid(ws, Z_i, Z_j, log_U_hat, log_V_hat, dq, phase):
-    """zigap.py:79-95 inside the models (D_hat = 1 at every non-zero count) on a HYBRID layout: the pCMF nest of zq_gap with
-    the D_hat[i, k] weight of zigap.py:94 (`dq`, kept under reference_quirks) on the gene side -- the column pass and the
-    dense gene-side kernel then run against FU * dq instead of FU, the two slow paths weight their additions to Z_j."""
-    ct, K = ws.ct, ws.K
-    n, m, gd, dn = ct.n, ct.m, ct.gd, ct.dense
-    st = stream_ptr()
-    FVs, Cs = ptr(ws.FV) + 4 * gd * ws.Kp, ptr(ws.C) + 4 * gd * ws.Kp
-    if phase in ('all', 'rows'):
-        _check_f32(Z_i, (n, K)); _check_f32(Z_j, (m, K)); _check_f32(log_U_hat, (n, K)); _check_f32(log_V_hat, (m, K))
-        if dq is not None:
-            _check_f32(dq, (n, K))
-        gs = ws.row_gene_splits
-        zero_R = ws.R if ct.ms == 0 else None
-        factor_prep_pair(ws, log_U_hat, log_V_hat, clear=(Z_i, Z_j, ws.C, ws.tile_flag, zero_R))
-        if ct.ms > 0:
-            with _span(ws, 'row_pass'):
-                if gs > 1:
-                    call('oriana_row_pass_split', ct.sparse_struct, ptr(ws.FU), FVs, ptr(ws.R), ptr(ws.s_cs), ptr(ws.tile_flag), K, gs, st)
-                else:
-                    call('oriana_row_pass', ct.sparse_struct, ptr(ws.FU), FVs, None, ptr(ws.R), ptr(ws.s_cs), None, None,
-                         ptr(ws.tile_flag), K, st)
-        with _span(ws, 'dense_images'):
-            call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
-        with _span(ws, 'dense_row'):
-            call('oriana_dense_row_pass', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S), ptr(ws.dn_flag), K,
-                 ws.dn_gene_splits, st)
-        with _span(ws, 'fixup'):
-            if ct.ms > 0:
-                call('oriana_fixup', ct.sparse_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat), ptr(log_V_hat),
-                     None, None, None, ptr(dq), ptr(Z_i), ptr(Z_j), None, K, 4 if dq is not None else 0, st)
-            call('oriana_dense_fixup_weighted', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
-                 ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(dq), K, st)
-        call('oriana_finalize_slabs', ptr(Z_i), ptr(ws.FU), ptr(ws.R), gs, ptr(ct.row_perm), n, K, st)
-    if phase == 'rows':
-        return
-    G = ws.FU
-    if dq is not None:
-        G = ws.extra('GQ', n)
-        call('oriana_scale_factor', ptr(G), ptr(ws.FU), ptr(dq), ptr(ct.row_perm), n, K, 0, st)
-    if ct.ms > 0:
-        with _span(ws, 'col_pass'):
-            col_pass(ct, ws.s_cs, G, ws.C, K, C_ptr=Cs)
-    with _span(ws, 'dense_images'):
-        call('oriana_dense_images', ptr(ws.dn_imgU), ptr(G), n, K, 1, st)
-    with _span(ws, 'dense_col'):
-        call('oriana_dense_col_pass', dn.c_struct, ptr(ws.dn_imgU), ptr(ws.dn_S), ptr(ws.C), K, ws.dn_cell_splits, st)
-    call('oriana_finalize', ptr(Z_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), m, K, 1, st)
 
 
 def _stateless_ws(n, m, K, X):

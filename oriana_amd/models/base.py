@@ -62,9 +62,11 @@ class FactorModel:
         already resident, sparse or row-sharded (``seed`` keys them by global row).
     device : torch device (default cuda).  process_group : torch.distributed group for row sharding.
     reference_quirks : reproduce zigap.py:94 (``D_hat[i, k]``) -- see SURVEY.md 8(a) policy.
-    dense_density : pCMF and ZI-pCMF -- genes expressed in at least this share of the cells are evaluated densely on the bf16
-        matrix cores in float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip; inside the
-        ZI model D_hat = 1 at every non-zero count, so its nest is the pCMF nest plus the D_hat[i, k] weight on the gene side).
+    dense_density : genes expressed in at least this share of the cells are evaluated densely on the bf16 matrix cores in
+        float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip).  Every model takes it:
+        inside the ZI models D_hat = 1 at every non-zero count, so their nest is the pCMF nest plus the D_hat[i, k] weight
+        on the gene side; the sparse models' den runs against the masked FV image, their accumulation against FV * S_hat,
+        their log sums through a second gene-side pass.
         ``'auto'``: engine.auto_dense_density -- engine.DENSE_DENSITY_DEFAULT (or the environment's ORIANA_DENSE_DENSITY;
         ``0`` / ``off`` disables) for matrices of at least 2e8 entries and a K the dense kernels are compiled for; ignored
         for a prebuilt ``engine.CountTiles`` (its own layout is used).
@@ -96,8 +98,6 @@ class FactorModel:
         dd = self._dense_density(dense_density, cmatrix, n_total, init)
         if isinstance(cmatrix, engine.CountTiles):
             self.counts = cmatrix
-            if cmatrix.gd and self.sparse:
-                raise ValueError('a hybrid (dense-gene) count layout serves pCMF (GaP) and ZI-pCMF (ZIGaP) only')
         elif _is_sparse_input(cmatrix):
             A = cmatrix._sparse if hasattr(cmatrix, '_sparse') else cmatrix
             X_host = A                     # the host-side initialisation reads it in sparse form
@@ -164,11 +164,11 @@ class FactorModel:
 
     def _dense_density(self, dense_density, cmatrix, n_total, init=None):
         """The density threshold of the hybrid layout for this model, or None."""
-        if self.sparse or isinstance(cmatrix, engine.CountTiles):
+        if isinstance(cmatrix, engine.CountTiles):
             return None
-        if self.zi and isinstance(dense_density, str):
-            # ZI-pCMF takes the hybrid layout on request only ('auto' keeps it sliced: at the benchmark's 90 % zeros the dense
-            # block buys a few per cent, and every ZI configuration measured so far was measured sliced)
+        if (self.zi or self.sparse) and isinstance(dense_density, str):
+            # the ZI / sparse models take the hybrid layout on request only ('auto' keeps them sliced: at the benchmark's
+            # 90 % zeros the dense block is neutral for them -- profiles/r04_zigap_hybrid_ab.json -- and pays from ~50 % on)
             return None
         if isinstance(init, str) and init == 'nmf':      # the on-device NMF start walks the sliced layout only
             return None

@@ -173,5 +173,39 @@ def test_zq_zigap_hybrid_vs_oracle(eng, n, m, K, quirk):
     assert int(ws.dn_flag.sum().item()) > 0
     assert err_colrel(Zi.cpu().numpy(), r[0]) < RTOL
     assert err_colrel(Zj.cpu().numpy(), r[1]) < RTOL
-    with pytest.raises(Exception):                   # the sparse nests stay on the sliced layout
-        eng.zq(ws, Zi, Zj, None, c(lu), c(lv), S_tilde=c(np.ones((m, K), np.float32)), S_hat=c(np.ones((m, K), np.float32)))
+
+
+@pytest.mark.parametrize('n,m,K', [(300, 200, 50), (257, 160, 100), (400, 131, 64), (130, 96, 7)])
+def test_zq_sparse_hybrid_vs_oracle(eng, n, m, K):
+    """sparse_gap.py:81-97 through the hybrid layout against the C oracle: den against the masked FV image, the S_hat-weighted
+    row sums against FV * S_hat (oriana_dense_images2), both per-gene sums and the log sums; a dead gene inside the dense
+    block (every factor off: its tiles take the exact slow path and contribute zeros), a cell on the slow path."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(n + 17 * m + K)
+    dens = np.clip(rng.beta(1.0, 2.0, size=m), 0.01, 1.0)
+    dens[:40] = np.linspace(1.0, 0.4, 40)
+    X = _counts(rng, n, m, dens).astype(np.float32)
+    lu = (rng.normal(size=(n, K))).astype(np.float32)
+    lv = (rng.normal(size=(m, K)) - 0.5).astype(np.float32)
+    lu[3] -= 80.0
+    ps = rng.random((m, K))
+    St = (ps > 0.3).astype(np.float32); Sh = ps.astype(np.float32)
+    St[5] = 0                                        # a dead gene among the densest
+    ct = eng.CountTiles.from_dense(X, 'cuda', dense_density=0.3)
+    assert ct.gd >= 32 and 5 in ct.col_perm.cpu().numpy()[:ct.gd]
+    ws = eng.ZWorkspace(ct, K)
+    c = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+    eng.zq(ws, o[0], o[1], o[2], c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh))
+    r = [np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_sparse_gap(r[0], r[1], r[2], lu, lv, St, Sh, X)
+    for got, ref in zip(o, r):
+        assert err_colrel(got.cpu().numpy(), ref) < RTOL
+    assert not o[1].cpu().numpy()[5].any()
+    # and the sliced layout of the same matrix agrees to float32 rounding
+    ct0 = eng.CountTiles.from_dense(X, 'cuda')
+    ws0 = eng.ZWorkspace(ct0, K)
+    o0 = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+    eng.zq(ws0, o0[0], o0[1], o0[2], c(lu), c(lv), S_tilde=c(St), S_hat=c(Sh))
+    for a, b in zip(o, o0):
+        assert err_colrel(a.cpu().numpy(), b.cpu().numpy()) < 5e-6

@@ -218,6 +218,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         // ================= stage A: the matrix instructions of D(gt + 1), one per slot; beside them S(gt), the splits of
         // s and R's tail products
         bool allok = true;
+#ifdef ORIANA_DN_ABL_PKMUL
+        float pk_x = 0.f, pk_r = 0.f; bool pk_ok = true;
+#endif
         f4v tq[4];
         u4v a2[2][3];
         uint32_t sh = 0, sm = 0, sl = 0;                                   // bf16 parts of the even value of a pair
@@ -265,13 +268,30 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     // slow path clears it) and 0 in the registers that feed R
 #ifdef ORIANA_DN_ABL_NORCP
                     const float t = (float)xi * (ok ? den : NAN);
+#elif defined(ORIANA_DN_ABL_PKMUL)
+                    // analysis switch: the multiplications of a pair of values as one v_pk_mul_f32
+                    float t;
+                    if ((v & 1) == 0) { pk_x = (float)xi; pk_r = ok ? __builtin_amdgcn_rcpf(den) : NAN; t = 0.f; }
+                    else {
+                        typedef float f2p __attribute__((ext_vector_type(2)));
+                        f2p a_ = {pk_x, (float)xi}, b_ = {pk_r, ok ? __builtin_amdgcn_rcpf(den) : NAN}, c_;
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(c_) : "v"(a_), "v"(b_));
+                        t = c_.y;
+                        Tw[(8 * ((v - 1) >> 2) + ((v - 1) & 3)) * TS] = c_.x;
+                        l0[v - 1] = pk_ok ? c_.x : 0.f;
+                    }
+                    if ((v & 1) == 0) pk_ok = ok;
 #else
                     const float t = (float)xi * (ok ? __builtin_amdgcn_rcpf(den) : NAN);
 #endif
+#ifdef ORIANA_DN_ABL_PKMUL
+                    if (v & 1) { Tw[(8 * (v >> 2) + (v & 3)) * TS] = t; l0[v] = ok ? t : 0.f; }
+#else
 #ifndef ORIANA_DN_ABL_NODSW
                     Tw[(8 * (v >> 2) + (v & 3)) * TS] = t;
 #endif
                     l0[v] = ok ? t : 0.f;
+#endif
 #endif
                 } else if (it == 16) {
                     __builtin_amdgcn_wave_barrier();
@@ -363,7 +383,12 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
             __builtin_amdgcn_sched_barrier(0);
             if (u % 12 == 11) {          // the 32-gene partial sums join the running sums (float32, round to nearest)
 #pragma unroll
+#ifdef ORIANA_DN_ABL_SCALAR_ADD
+                // analysis switch: the 48 additions as scalar v_add_f32 (the compiler packs them into v_pk_add_f32)
+                for (int v = 0; v < 16; ++v) { float r_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r_) : "v"(rs[nt][v]), "v"(dv[v])); rs[nt][v] = r_; }
+#else
                 for (int v = 0; v < 16; ++v) rs[nt][v] += dv[v];
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

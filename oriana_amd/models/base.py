@@ -434,8 +434,10 @@ class FactorModel:
                  ptr(nz), K, st)
         zz = torch.zeros(2, dtype=torch.float64, device=dev)      # over Z - M: sum log(pi e^-Lambda + 1 - pi), sum Lambda^2
         if self.zi:
-            call('oriana_dropout_metric', ptr(zz), ptr(self._D_hat), ptr(U), ptr(V), ptr(self.pi_d.tensor),
-                 ptr(self._nzmask), n, m, K, st)
+            # (the gene axis of the dropout node's matrices is padded with inert genes to a multiple of 4, zigap.py _init_zi:
+            # pi_d = 0 there, so log(pi e^-Lambda + 1 - pi) = 0, and Lambda = 0)
+            call('oriana_dropout_metric', ptr(zz), ptr(self._Dp), ptr(U), ptr(self._padG(V, 'Vm')), ptr(self._padG(self.pi_d.tensor, 'pim')),
+                 ptr(self._nzmask), n, self._mp, K, st)
             odist.all_reduce_sum(zz, self.pg)
             odist.all_reduce_sum(nz, self.pg)
         else:

@@ -33,36 +33,58 @@ class _ZIMixin:
 
     def _init_zi(self):
         n, m, dev = self.n, self.m, self.device
+        # The dense ZI kernels move 16-byte pieces of D_hat rows, masks and logits (csrc/dense_zi.hip, dense_f32.hip): the
+        # gene axis of D_hat, of the non-zero mask and of every per-gene operand they take is padded to a multiple of 4
+        # with INERT genes -- no counts, V_hat row 0, pi_d 0 (so p_d = 1e-10 by the column override of zigap.py:133): they add
+        # nothing to D_hat V_hat, their rows of D_hat^T U_hat and of the column sums are dropped.  m % 4 == 0: nothing changes.
+        mp = self._mp = (m + 3) // 4 * 4
+        self._padbuf = {}
         self.pi_d = Parameter(torch.zeros(m, dtype=torch.float64, device=dev))
         # p_d = (X > 0) as float (zigap.py:77): exactly 1.0 at the non-zero counts, so D_hat holds it
         # exactly and the float64 matrix is only evaluated on access (LazyParameter)
-        self._D_hat = torch.zeros(n, m, dtype=torch.float32, device=dev)
+        self._Dp = torch.zeros(n, mp, dtype=torch.float32, device=dev)
+        self._D_hat = self._Dp[:, :m]                   # (n, m) view: what the model's own arithmetic and the API see
         ct = self.counts
-        call('oriana_dropout_fix_nz_ld', ct.sparse_struct, None, ptr(self._D_hat), 1.0, m, stream_ptr())
+        call('oriana_dropout_fix_nz_ld', ct.sparse_struct, None, ptr(self._Dp), 1.0, mp, stream_ptr())
         if ct.dense is not None:           # hybrid layout: the non-zero counts of the dense genes
-            call('oriana_dense_fix_nz', ct.dense.c_struct, ptr(self._D_hat), m, ptr(ct.row_perm), ptr(ct.col_perm), 1.0, stream_ptr())
+            call('oriana_dense_fix_nz', ct.dense.c_struct, ptr(self._Dp), mp, ptr(ct.row_perm), ptr(ct.col_perm), 1.0, stream_ptr())
         self.p_d = LazyParameter((n, m), dev, lambda: self._D_hat.double())
-        self._pd_sum = torch.zeros(m, dtype=torch.float64, device=dev)
+        self._pd_sum_p = torch.zeros(mp, dtype=torch.float64, device=dev)
+        self._pd_sum = self._pd_sum_p[:m]
         # bit mask of X != 0 (constant): lets the D update apply p_d[X != 0] = 1 - 1e-10 in its own pass
-        self._nzmask = torch.zeros(((n + 31) // 32) * max(m, 1), dtype=torch.int32, device=dev)
-        call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._D_hat), n, m, stream_ptr())
+        self._nzmask = torch.zeros(((n + 31) // 32) * max(mp, 1), dtype=torch.int32, device=dev)
+        call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._Dp), n, mp, stream_ptr())
         self._pd_sum_fresh = False
         # non-zero counts per gene (local rows): the float32 sweep kernel counts p_d = float32(1 - 1e-10) = 1 at the non-zeros;
         # the M-step takes the 1e-10 per entry back, as the reference's float64 mean has it (zigap.py:135, 158) -- a gene
         # expressed in every cell then gets pi_d = 1 - 1e-10 (finite logit), not 1
-        self._nnz_gene = torch.zeros(m, dtype=torch.float64, device=dev)
-        call('oriana_colsum_wide_f32', ptr(self._nnz_gene), ptr(self._D_hat), n, m, stream_ptr())
+        self._nnz_gene_p = torch.zeros(mp, dtype=torch.float64, device=dev)
+        self._nnz_gene = self._nnz_gene_p[:m]
+        call('oriana_colsum_wide_f32', ptr(self._nnz_gene_p), ptr(self._Dp), n, mp, stream_ptr())
         # float32 matrix-core path of the sweep (dense_f32.hip) and the D_hat V product it leaves for the next sweep,
         # valid while (D_hat, V_hat, S_hat) are the tensors it was formed from: _ver counts their writes
         self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
         self._DV_next = None
         self.n_kept_products = 0          # sweeps whose D_hat V came from the previous sweep's D update
         from .. import _lib
-        self._lg_scratch = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, self.k)), dtype=torch.float32, device=dev)
+        self._lg_scratch = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(mp, self.k)), dtype=torch.float32, device=dev)
         self._dt_scratch = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, self.k)), dtype=torch.float32, device=dev)
         # how the float32 products are evaluated (include/oriana_hip.h): 1 = three-way bf16 splits on the bf16 matrix
-        # cores (K <= 100; K <= 64 when the gene count is not a multiple of 4), 0 = the float32 matrix instruction
+        # cores (K <= 100), 0 = the float32 matrix instruction
         self._matrix_arith = {'f32': 0, 'bf16x3': 1}[os.environ.get('ORIANA_ZI_MATRIX', 'bf16x3')]
+
+    def _padG(self, T, key):
+        """A per-gene operand ((m, K) or (m,) float64) with the inert genes appended as zeros; T itself when m % 4 == 0."""
+        if T is None:
+            return None
+        if self._mp == self.m:
+            return T.contiguous()
+        buf = self._padbuf.get(key)
+        shape = (self._mp,) + tuple(T.shape[1:])
+        if buf is None or buf.shape != shape or buf.dtype != T.dtype:
+            buf = self._padbuf[key] = torch.zeros(shape, dtype=T.dtype, device=self.device)
+        buf[:self.m].copy_(T)
+        return buf
 
     @property
     def D_hat(self):
@@ -86,11 +108,11 @@ class _ZIMixin:
             if self.p_d.materialised:
                 call('oriana_colsum_wide_f64', ptr(self._pd_sum), ptr(self.p_d.tensor), self.n, self.m, st)
             elif self._pd_snap is None:                 # p_d == D_hat exactly (zigap.py:77)
-                call('oriana_colsum_wide_f32', ptr(self._pd_sum), ptr(self._D_hat), self.n, self.m, st)
+                call('oriana_colsum_wide_f32', ptr(self._pd_sum_p), ptr(self._Dp), self.n, self._mp, st)
             else:                                       # re-evaluate the sums only, nothing is stored
                 U, V, pi_d = self._pd_snap
-                call('oriana_dropout_update_fused', None, None, ptr(U), ptr(V), ptr(pi_d), ptr(self._nzmask),
-                     ptr(self._pd_sum), self.n, self.m, self.k, st)
+                call('oriana_dropout_update_fused', None, None, ptr(U), ptr(self._padG(V, 'Vs')), ptr(self._padG(pi_d, 'pis')),
+                     ptr(self._nzmask), ptr(self._pd_sum_p), self.n, self._mp, self.k, st)
         self._pd_sum_fresh = False
         odist.all_reduce_sum(self._pd_sum, self.pg)
         torch.div(self._pd_sum, float(self.n_total), out=self.pi_d.tensor)
@@ -107,44 +129,45 @@ class _ZIMixin:
             return kept[0]
         out = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
         with engine._span(self._ws, 'DV'):
-            call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(V.contiguous()), self.n, self.m, self.k, 0,
+            call('oriana_dense_times_factor', ptr(out), ptr(self._Dp), ptr(self._padG(V, 'Vt')), self.n, self._mp, self.k, 0,
                  stream_ptr())
         return out
 
     def _Dt_times(self, U):
         """np.dot(D_hat.T, U) (zigap.py:124) over the LOCAL rows: the shards' partials are summed by the sweep's
         packed exchange.  (m, K)."""
-        out = torch.zeros(self.m, self.k, dtype=torch.float64, device=self.device)
+        out = torch.zeros(self._mp, self.k, dtype=torch.float64, device=self.device)
         with engine._span(self._ws, 'DtU'):
             if self._fast_dense:
-                call('oriana_dense_t_times_factor_f32', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), ptr(self._dt_scratch),
-                     self._matrix_arith, self.n, self.m, self.k, stream_ptr())
+                call('oriana_dense_t_times_factor_f32', ptr(out), ptr(self._Dp), ptr(U.contiguous()), ptr(self._dt_scratch),
+                     self._matrix_arith, self.n, self._mp, self.k, stream_ptr())
             else:
-                call('oriana_dense_times_factor', ptr(out), ptr(self._D_hat), ptr(U.contiguous()), self.n, self.m,
+                call('oriana_dense_times_factor', ptr(out), ptr(self._Dp), ptr(U.contiguous()), self.n, self._mp,
                      self.k, 1, stream_ptr())
-        return out
+        return out[:self.m]                              # (the inert genes' rows are dropped)
 
     def _update_D(self, V_for_d, V_next=None):
         """zigap.py:130-136: p_d = sigmoid(logit(pi_d) - U_hat V^T), overrides, D_hat; one fused
         kernel that stores D_hat and leaves the column sums of p_d for the pi_d M-step.  The float64
         p_d itself is not stored: it is re-evaluated on access from a snapshot of the three inputs.
         V_next: the factor the next sweep's cell update multiplies D_hat with, as it stands now."""
-        self._pd_sum.zero_()
+        self._pd_sum_p.zero_()
         V = V_for_d.contiguous()
+        Vp, pip = self._padG(V, 'Vd'), self._padG(self.pi_d.tensor, 'pid')
         with engine._span(self._ws, 'D_update'):
             if self._fast_dense:
                 DV = None
                 if V_next is not None:
                     DV = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
-                    V_next = V_next.contiguous()
-                call('oriana_dropout_sweep_fused', ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
-                     ptr(self._nzmask), ptr(self._pd_sum), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self._matrix_arith,
-                     self.n, self.m, self.k, stream_ptr())
+                    V_next = Vp if V_next is V_for_d else self._padG(V_next, 'Vn')
+                call('oriana_dropout_sweep_fused', ptr(self._Dp), ptr(self._U_hat), ptr(Vp), ptr(pip),
+                     ptr(self._nzmask), ptr(self._pd_sum_p), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self._matrix_arith,
+                     self.n, self._mp, self.k, stream_ptr())
                 self._pd_sum.sub_(self._nnz_gene, alpha=1e-10)      # the non-zeros are 1 - 1e-10 each, not 1
             else:
                 DV = None
-                call('oriana_dropout_update_fused', None, ptr(self._D_hat), ptr(self._U_hat), ptr(V), ptr(self.pi_d.tensor),
-                     ptr(self._nzmask), ptr(self._pd_sum), self.n, self.m, self.k, stream_ptr())
+                call('oriana_dropout_update_fused', None, ptr(self._Dp), ptr(self._U_hat), ptr(Vp), ptr(pip),
+                     ptr(self._nzmask), ptr(self._pd_sum_p), self.n, self._mp, self.k, stream_ptr())
         self._touch()
         self._DV_next = (DV, self._ver) if DV is not None else None
         self._pd_sum_fresh = True
@@ -152,10 +175,10 @@ class _ZIMixin:
         self.p_d.defer(lambda: self._evaluate_p_d(*snap))
 
     def _evaluate_p_d(self, U, V, pi_d):
-        p_d = torch.empty(self.n, self.m, dtype=torch.float64, device=self.device)
-        call('oriana_dropout_update_fused', ptr(p_d), None, ptr(U), ptr(V), ptr(pi_d), ptr(self._nzmask), None,
-             self.n, self.m, self.k, stream_ptr())
-        return p_d
+        p_d = torch.empty(self.n, self._mp, dtype=torch.float64, device=self.device)
+        call('oriana_dropout_update_fused', ptr(p_d), None, ptr(U), ptr(self._padG(V, 'Vs')), ptr(self._padG(pi_d, 'pis')),
+             ptr(self._nzmask), None, self.n, self._mp, self.k, stream_ptr())
+        return p_d if self._mp == self.m else p_d[:, :self.m].contiguous()
 
 
 class _SparseMixin:
@@ -235,7 +258,7 @@ class ZIGaP(_ZIMixin, FactorModel):
         if self.reference_quirks:
             # zigap.py:94 weights the per-gene sums with D_hat[i, k] (first K gene columns)
             dq = torch.empty(self.n, self.k, dtype=torch.float32, device=self.device)
-            call('oriana_take_cols_f32', ptr(dq), ptr(self._D_hat), self.n, self.m, self.k, stream_ptr())
+            call('oriana_take_cols_f32', ptr(dq), ptr(self._Dp), self.n, self._mp, self.k, stream_ptr())
         zq_args = (self._ws, self._Zi, self._Zj, None, self._log_U_hat, self._log_V_hat)
         engine.zq(*zq_args, dq=dq, phase='rows')
         # U_q: a2 = alpha2 + D_hat V_hat (OLD V_hat)                                  zigap.py:115-120

@@ -264,6 +264,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # collectives of one sweep's exchange (counted over the sweeps run so far: warm-up + timed)
+    coll_per_sweep = round(model._xch.n_collectives / max(model._xch.n_reduces, 1))
     value = args.steps / elapsed
     step_ms = sorted(a.elapsed_time(b) for a, b in marks.values())
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -343,7 +345,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                        'n_cells': n_total, 'n_genes': m, 'K': K, 'nnz': nnz_total, 'rows_per_rank': n,
                        'parallelism': 'rows/%d' % world, 'setup_s': round(t_setup, 1),
                        'hbm_gb_rank0': round(torch.cuda.max_memory_allocated() / 1e9, 1),
-                       'collectives_per_sweep': (2 + (1 if model.zi else 0)) if (world > 1 or odist.sharded()) else 0,
+                       'collectives_per_sweep': (coll_per_sweep + (1 if model.zi else 0)) if (world > 1 or odist.sharded()) else 0,
                        'layout': ('hybrid: %d genes (expressed in >= %.0f%% of the cells, %.1f%% of the non-zeros) as a dense block on the '
                                   'bf16 matrix cores (float32-equivalent: exact three-way splits, six cross products), %d genes sliced'
                                   % (counts.gd, 100.0 * counts.dense_density, 100.0 * counts.dense.nnz / max(counts.nnz, 1), counts.ms))
@@ -416,7 +418,9 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
             out['allreduce_ms'] = allreduce_ms
             out['allreduce_share_of_step'] = allreduce_ms / ms_per_step if ms_per_step > 0 else None
             out['exchange_bytes'] = int(model._xch.numel * 4)
-            out['exchange'] = 'one step per sweep: float32 all-reduce of the per-gene sums + float64 all-reduce of the (small) rate partials'
+            out['exchange'] = ('one step per sweep: float64 all-reduce of the (small) rate partials, started before the column pass; float32 '
+                               'all-reduce of the per-gene sums -- pCMF with K == Kp: in packed gene order, the sliced genes\' segment started '
+                               'before the dense gene-side kernel, the dense genes\' segment after it')
         if stateless is not None:
             out['stateless_binding'] = stateless
         if world == 1 and odist.sharded():

@@ -263,11 +263,12 @@ int oriana_dense_fixup_weighted(const oriana_dense *d, const int32_t *flag, floa
                                 const int32_t *row_perm, const int32_t *col_perm, float *Z_hat_i, float *Z_hat_j,
                                 const float *dq, int64_t K, void *stream);
 /* The slow path of every nest: Z_log (zigap.py:95, sparse_gap.py:97; may be NULL), the D_hat[i, k] weight (dq, may be NULL),
- * the masks of the sparse models (S_tilde, S_hat: both or neither; (m, K) float32, caller's gene order). */
+ * the masks of the sparse models (S_tilde, S_hat: both or neither; (m, K) float32, caller's gene order).  zj_packed != 0:
+ * Z_hat_j is indexed by the PACKED gene index (the row-sharded pCMF sweep exchanges the per-gene sums in packed order). */
 int oriana_dense_fixup_variant(const oriana_dense *d, const int32_t *flag, float *S, const float *logU, const float *logV,
                                const int32_t *row_perm, const int32_t *col_perm, float *Z_hat_i, float *Z_hat_j,
                                float *Z_log, const float *dq, const float *S_tilde, const float *S_hat, int64_t K,
-                               void *stream);
+                               int zj_packed, void *stream);
 /* oriana_dense_images with the second image (the operand of the accumulation R += S F2 and its tail pieces) taken from F2:
  * the sparse models accumulate against FV * S_hat while den runs against the masked FV (sparse_gap.py:88-95). */
 int oriana_dense_images2(void *img, const float *F, const float *F2, int64_t rows, int64_t K, int side, void *stream);

@@ -64,7 +64,7 @@ _SIGS = {
     'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_dense_metric': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_dense_fixup_weighted': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    'oriana_dense_fixup_variant': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_dense_fixup_variant': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, c_int, _P]),
     'oriana_dense_images2': (c_int, [_P, _P, _P, _I, _I, c_int, _P]),
     'oriana_dense_fix_nz': (c_int, [ctypes.POINTER(OrianaDense), _P, _I, _P, _P, c_double, _P]),
     'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
                                                   const int32_t *__restrict__ col_perm, float *__restrict__ Zi,
                                                   float *__restrict__ Zj, int64_t n, int ngt, int K,
                                                   const float *__restrict__ dq, const float *__restrict__ S_tilde,
-                                                  const float *__restrict__ S_hat, float *__restrict__ Zlog) {
+                                                  const float *__restrict__ S_hat, float *__restrict__ Zlog, int zj_packed) {
     __shared__ int nhit;
     __shared__ int hits[256];
     const int64_t ct = blockIdx.x;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_dn_fixup(const uint16_t *__restrict__ X
                 const float vi = sh ? sh[k] * expectation : expectation;               // sparse_gap.py:95
                 if (vi != 0.f) atomicAdd(&Zi[i * K + k], vi);
                 const float vj = dq ? dq[i * K + k] * expectation : expectation;        // zigap.py:94 (D_hat[i, k])
-                if (vj != 0.f) atomicAdd(&Zj[j * K + k], vj);
+                if (vj != 0.f) atomicAdd(&Zj[(zj_packed ? jp : j) * K + k], vj);
                 if (Zlog) {
                     const float vl = expectation * ls;                                  // zigap.py:95 / sparse_gap.py:97
                     if (vl != 0.f) atomicAdd(&Zlog[j * K + k], vl);
@@ -922,13 +922,13 @@ extern "C" int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, co
 extern "C" int oriana_dense_fixup_variant(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
                                           const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
                                           float *Zj, float *Zlog, const float *dq, const float *S_tilde, const float *S_hat,
-                                          int64_t K, void *stream) {
+                                          int64_t K, int zj_packed, void *stream) {
     if (!dense_ok(d) || K <= 0) return ORIANA_EINVAL;
     if (d->gd == 0 || d->n == 0) return 0;
     if (!flag || !S || !logU || !logV || !Zi || !Zj || ((S_tilde == nullptr) != (S_hat == nullptr))) return ORIANA_EINVAL;
     const int ngt = (int)(d->gd / 32);
     hipLaunchKernelGGL(k_dn_fixup, dim3((unsigned)d->nct), dim3(256), 0, (hipStream_t)stream, d->x, S,
-                       flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K, dq, S_tilde, S_hat, Zlog);
+                       flag, logU, logV, row_perm, col_perm, Zi, Zj, d->n, ngt, (int)K, dq, S_tilde, S_hat, Zlog, zj_packed);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
@@ -936,7 +936,7 @@ extern "C" int oriana_dense_fixup_variant(const oriana_dense *d, const int32_t *
 extern "C" int oriana_dense_fixup_weighted(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,
                                            const float *logV, const int32_t *row_perm, const int32_t *col_perm, float *Zi,
                                            float *Zj, const float *dq, int64_t K, void *stream) {
-    return oriana_dense_fixup_variant(d, flag, S, logU, logV, row_perm, col_perm, Zi, Zj, nullptr, dq, nullptr, nullptr, K, stream);
+    return oriana_dense_fixup_variant(d, flag, S, logU, logV, row_perm, col_perm, Zi, Zj, nullptr, dq, nullptr, nullptr, K, 0, stream);
 }
 
 extern "C" int oriana_dense_fixup(const oriana_dense *d, const int32_t *flag, float *S, const float *logU,

@@ -984,9 +984,11 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
                 }
                 if (Zj) {
                     float v = expectation;
-                    if (quirk && dq) v = dq[i * K + k] * expectation;   // zigap.py:94 (D_hat[i, k])
+                    if ((quirk & 1) && dq) v = dq[i * K + k] * expectation;   // zigap.py:94 (D_hat[i, k])
                     else if (w_nz) v = w * expectation;                 // sparse_zigap.py:115
-                    if (v != 0.f) atomicAdd(&Zj[j * K + k], v);
+                    // (quirk bit 1: Zj is indexed by the PACKED gene index -- the sharded pCMF sweep exchanges the per-gene
+                    //  sums in packed order, engine.zq_gap zj_packed)
+                    if (v != 0.f) atomicAdd(&Zj[((quirk & 2) ? jp : j) * K + k], v);
                 }
                 if (Zlog) {
                     const float v = (w_nz ? w * expectation : expectation) * ls;   // zigap.py:95
@@ -2642,9 +2644,9 @@ extern "C" int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag, f
     const int64_t nt = cm->nrb * cm->ncb;
     if (nt == 0 || cm->nnz == 0) return 0;
     if (!tile_flag || !s_cs || !logU || !logV) return ORIANA_EINVAL;
-    const int quirk = (variant & 4) ? 1 : 0;
+    const int quirk = ((variant & 4) ? 1 : 0) | ((variant & 8) ? 2 : 0);       // bit 1: Z_hat_j indexed by the packed gene
     // (K <= number of genes is the caller's to check: cm->m of the sliced part of a hybrid layout counts its own genes only)
-    if (quirk && !dq) return ORIANA_EQUIRK;
+    if ((quirk & 1) && !dq) return ORIANA_EQUIRK;
     hipLaunchKernelGGL(k_fixup, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, tile_flag, s_cs,
                        sw_cs, s_rs, logU, logV, S_tilde, S_hat, w_nz, dq, Zi, Zj, Zlog, (int)K, quirk);
     ORIANA_LAUNCH_CHECK();

@@ -155,7 +155,8 @@ class SweepExchange:
         if not self.active:
             return
         self.n_reduces += 1
-        bufs = [self.buf] if self.numel32 else []
+        bufs = [self.buf] if (self.numel32 and not self._parts32) else []
+        self._parts32 = False
         if self.numel64 and not self._started64:
             bufs.append(self.buf64)
         self._started64 = False
@@ -169,6 +170,20 @@ class SweepExchange:
             self.wait()
 
     _started64 = False
+    _parts32 = False
+
+    def reduce_rows_async(self, name, lo, hi):
+        """Start the all-reduce of rows [lo, hi) of the float32 segment `name` NOW, asynchronously (the segment is written
+        in an order that makes them final early: engine.zq_gap zj_packed).  The next reduce() then sends no float32 buffer
+        and only waits.  A sweep that uses this must cover every row of every float32 segment with such calls."""
+        if not self.active or hi <= lo:
+            return
+        o, c, shape = self._seg32[name]
+        width = c // shape[0]
+        self.n_collectives += 1
+        self._pending.append(dist.all_reduce(self.buf[o + lo * width:o + hi * width], op=dist.ReduceOp.SUM, group=self.pg,
+                                             async_op=True))
+        self._parts32 = True
 
     def start64(self):
         """Start the float64 all-reduce NOW, asynchronously: its partials (the cell-side column sums, D_hat^T U_hat)

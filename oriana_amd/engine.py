@@ -665,7 +665,8 @@ def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K, goff=0):
     return rc == 0
 
 
-def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_rows=True, finalize_cols=True, clear=()):
+def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_rows=True, finalize_cols=True, clear=(),
+           zj_packed=False, on_segment=None):
     """GaP.compute_Z_q_expectations (reference gap.py:67-80) on the resident tiles: outputs first,
     zero-filled by the callee, returns None.  `phase`: 'rows' stops once Z_hat_i is final (factor
     preparation, row pass, slow path, row-side finalize), 'cols' does the rest (column pass, gene-side finalize):
@@ -673,7 +674,12 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
     partial of its single exchange ready when the column pass ends.
     finalize_rows / finalize_cols = False: the caller completes Z_hat_i / Z_hat_j itself (the pCMF sweep folds
     Z += F * R into its Gamma updates, oriana_gamma_update_finalize); until then they hold the slow path's additions
-    only.  `clear`: further buffers (at most 3) zero-filled by the factor preparation's launch."""
+    only.  `clear`: further buffers (at most 3) zero-filled by the factor preparation's launch.
+    zj_packed (the row-sharded pCMF sweep): Z_hat_j is kept in the PACKED gene order -- the slow paths index it by the packed
+    gene, the gene-side finalize writes it without the permutation -- so that the dense genes [0, gd) and the sliced genes
+    [gd, m) are two contiguous segments of the exchange buffer; `on_segment(lo, hi)` is called as soon as the rows
+    [lo, hi) of Z_hat_j are final (the sliced segment after the sliced column pass, i.e. BEFORE the dense gene-side
+    kernel runs: its all-reduce travels under that kernel)."""
     ct, K = ws.ct, ws.K
     st = stream_ptr()
     dn = ct.dense
@@ -703,24 +709,35 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
                      ptr(ws.dn_flag), K, ws.dn_gene_splits, st)
         with _span(ws, 'fixup'):
             if ct.ms > 0:
+                # (packed Z_hat_j: the sliced part's packed gene 0 is row gd of the buffer)
                 call('oriana_fixup', ct.sparse_struct, ptr(ws.tile_flag), ptr(ws.s_cs), None, None, ptr(log_U_hat),
-                     ptr(log_V_hat), None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j), None, K, 0, st)
+                     ptr(log_V_hat), None, None, None, None, ptr(Z_hat_i), ptr(Z_hat_j) + (4 * gd * K if zj_packed else 0), None, K,
+                     8 if zj_packed else 0, st)
             if dn is not None:
-                call('oriana_dense_fixup', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
-                     ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_hat_i), ptr(Z_hat_j), K, st)
+                call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
+                     ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_hat_i), ptr(Z_hat_j), None, None, None, None, K,
+                     1 if zj_packed else 0, st)
         if finalize_rows:
             call('oriana_finalize_slabs', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), gs, ptr(ct.row_perm), ct.n, K, st)
     if phase in ('all', 'cols'):
         if ct.ms > 0:
             with _span(ws, 'col_pass'):
                 col_pass(ct, ws.s_cs, ws.FU, ws.C, K, C_ptr=Cs)
+            if zj_packed:                   # the sliced genes' rows of Z_hat_j are final: hand them to the exchange
+                call('oriana_finalize', ptr(Z_hat_j) + 4 * gd * K, FVs, Cs, None, None, ct.ms, K, 1, st)
+                if on_segment is not None:
+                    on_segment(gd, ct.m)
         if dn is not None:
             with _span(ws, 'dense_images'):
                 call('oriana_dense_images', ptr(ws.dn_imgU), ptr(ws.FU), ct.n, K, 1, st)
             with _span(ws, 'dense_col'):
                 call('oriana_dense_col_pass', dn.c_struct, ptr(ws.dn_imgU), ptr(ws.dn_S), ptr(ws.C), K,
                      ws.dn_cell_splits, st)
-        if finalize_cols:
+            if zj_packed:
+                call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, None, gd, K, 1, st)
+                if on_segment is not None:
+                    on_segment(0, gd)
+        if finalize_cols and not zj_packed:
             call('oriana_finalize', ptr(Z_hat_j), ptr(ws.FV), ptr(ws.C), None, ptr(ct.col_perm), ct.m, K, 1, st)
 
 
@@ -813,7 +830,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
                      ws.dn_gene_splits, st)
             with _span(ws, 'fixup'):
                 call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
-                     ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, st)
+                     ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, 0, st)
         call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), n, K, 1, st)
         if Z_log is not None:
             # E[log U]-weighted row factor of the log sums: built NOW, from the pre-update E[log U] (the caller

@@ -162,3 +162,50 @@ def test_exchange_single_process_is_exact():
     xch.put64('sumU', t)
     xch.reduce()
     assert xch.n_reduces == 0 and xch.get64('sumU') is t
+
+
+def _segment_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oriana_amd import dist as odist
+        m, K, gd = 37, 4, 11
+        rng = np.random.default_rng(200 + rank)
+        zj = rng.gamma(2.0, 50.0, size=(m, K)).astype(np.float32)
+        sums = np.stack([rng.gamma(2.0, 1e6, size=K), -rng.gamma(2.0, 1e5, size=K)])
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+        xch = odist.SweepExchange('cpu', dist.group.WORLD, {'Zj': (m, K)}, {'sumU': (2, K)})
+        xch.put64('sumU', torch.from_numpy(sums))
+        xch.start64()                                             # before the column pass
+        xch.f32['Zj'][gd:].copy_(torch.from_numpy(zj[gd:]))       # the sliced genes' rows are final first ...
+        xch.reduce_rows_async('Zj', gd, m)
+        xch.f32['Zj'][:gd].copy_(torch.from_numpy(zj[:gd]))       # ... then the dense genes'
+        xch.reduce_rows_async('Zj', 0, gd)
+        xch.reduce()                                              # nothing left to send: waits
+        dist.all_reduce = real
+        assert calls == [2 * K, (m - gd) * K, gd * K] and xch.n_reduces == 1 and xch.n_collectives == 3
+        got = dict(Zj=xch.f32['Zj'].numpy().copy(), sumU=xch.get64('sumU').numpy().copy())
+        # the next sweep without segments falls back to the whole buffer
+        xch.put64('sumU', torch.from_numpy(sums))
+        xch.reduce()
+        assert xch.n_reduces == 2 and xch.n_collectives == 5
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(Zj=zj, sumU=sums))
+        if rank == 0:
+            exact = {k: sum(g[k].astype(np.float64) for g in gathered) for k in got}
+            np.savez(out, **{'got_' + k: v for k, v in got.items()}, **{'ref_' + k: v for k, v in exact.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_in_segments(tmp_path):
+    """The packed per-gene sums travel in two segments, each started as soon as it is final (SweepExchange.reduce_rows_async:
+    the sliced genes' rows before the dense gene-side kernel runs); reduce() then only waits.  Sums exact to float32."""
+    out = str(tmp_path / 'seg.npz')
+    mp.spawn(_segment_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    assert float((np.abs(r['got_Zj'] - r['ref_Zj']) / np.abs(r['ref_Zj'])).max()) < 2e-7
+    assert float((np.abs(r['got_sumU'] - r['ref_sumU']) / np.abs(r['ref_sumU'])).max()) < 1e-15

@@ -212,8 +212,8 @@ def _hybrid_worker(rank, world, port, X, K, a1, b1, out):
 
 def test_four_ranks_hybrid_layout_uneven_split(tmp_path):
     """Four row shards of 5003 cells (1250, 1250, 1250 and the remainder 1253) with the HYBRID layout: every rank picks
-    the same dense genes and gene order from the all-reduced counts, one exchange (float32 + float64 all-reduce) per
-    sweep, and the single-process run is reproduced to summation order.  (A GPU box admits six processes on its card:
+    the same dense genes and gene order from the all-reduced counts, one exchange per sweep (the float64 partials and the
+    two segments of the packed float32 per-gene sums), and the single-process run is reproduced to summation order.  (A GPU box admits six processes on its card:
     four ranks + this one.)"""
     import oriana_amd.models as M
     rng = np.random.default_rng(21)
@@ -226,7 +226,9 @@ def test_four_ranks_hybrid_layout_uneven_split(tmp_path):
     got = np.load(out)
     assert int(got['gd']) >= 32
     assert got['shards'].tolist() == [[0, 1250], [1250, 2500], [2500, 3750], [3750, 5003]]
-    assert float(got['per_sweep']) == 2.0
+    # one exchange per sweep, in three collectives: the float64 partials (started before the column pass), the sliced genes'
+    # segment of the packed float32 per-gene sums (started before the dense gene-side kernel), the dense genes' segment
+    assert float(got['per_sweep']) == 3.0
     single = M.GaP(X, k=K, init=(a1, b1), dense_density=0.25)
     assert single.counts.gd == int(got['gd'])
     single.fit(2)
@@ -259,7 +261,7 @@ def test_bench_self_launch_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
-    assert d['config']['collectives_per_sweep'] == 2       # one exchange: float32 per-gene sums + float64 rate partials
+    assert d['config']['collectives_per_sweep'] == 3       # one exchange: float64 rate partials + the two segments of the packed per-gene sums
     assert len(d['per_rank_ms']['ranks']) == 2 and d['allreduce_ms'] > 0
     assert d['exchange_bytes'] == (30000 * 100 + 4 * 100) * 4
     assert 'K=100' in d['metric'] and '125k' in d['metric']
@@ -291,7 +293,7 @@ def test_rccl_single_rank_rehearsal():
     # every sweep (1 warm-up + 4 timed + the un-instrumented loop of a launch-bound workload) is one exchange of two
     # collectives (float64 partials started before the column pass, float32 per-gene sums after it)
     assert d['exchange_rehearsal']['exchanges'] >= 5
-    assert d['exchange_rehearsal']['collectives'] == 2 * d['exchange_rehearsal']['exchanges']
+    assert d['exchange_rehearsal']['collectives'] == 2 * d['exchange_rehearsal']['exchanges']      # (c2: sliced layout, one segment)
     assert d['config']['collectives_per_sweep'] == 2
     assert 'exchange_rehearsal' not in out['plain']
     assert abs(d['check'] / out['plain']['check'] - 1.0) < 1e-6

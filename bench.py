@@ -219,11 +219,16 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     dd = None
     if mname == 'GaP' and engine.dense_supported(K):
         dd = engine.auto_dense_density(n_total, m, K) if args.dense_density == 'auto' else (float(args.dense_density) or None)
-    elif mname in ('ZIGaP', 'SparseGaP') and engine.dense_supported(K) and args.dense_density != 'auto':
-        dd = float(args.dense_density) or None        # (ZI-pCMF: the hybrid layout on request only)
+    min_share = 0.0
+    if mname in ('ZIGaP', 'SparseGaP') and engine.dense_supported(K):
+        # the ZI / sparse models' 'auto': the dense block only when its genes hold >= 75 % of the non-zeros (models/base.py)
+        if args.dense_density == 'auto':
+            dd, min_share = engine.auto_dense_density(n_total, m, K), 0.75
+        else:
+            dd = float(args.dense_density) or None
     counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
                                            reduce_fn=(lambda t: odist.all_reduce_sum(t)) if (world > 1 or odist.sharded()) else None,
-                                           dense_density=dd, n_total=n_total)
+                                           dense_density=dd, n_total=n_total, dense_min_share=min_share)
     a1, b1 = gen.initial_shapes()
     model = getattr(models, mname)(counts, k=K, use_factors=False, init=(a1, b1), device=dev,
                                    process_group=(dist.group.WORLD if (world > 1 or odist.sharded()) else None), n_total=n_total)

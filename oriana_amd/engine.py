@@ -76,15 +76,21 @@ class CountTiles:
         self.col_perm = order.to(torch.int32).contiguous()
 
     @staticmethod
-    def dense_order(col_nnz, n_total, bad, density):
+    def dense_order(col_nnz, n_total, bad, density, min_share=0.0):
         """(gene order, gd) of a hybrid layout: genes whose share of non-zero cells is >= `density` and whose counts
         are all integers in [0, 65535) (`bad`: per-gene number of entries that are not) come first, in decreasing
-        order of their non-zero count, cut to a multiple of 32; the rest follows in decreasing order."""
+        order of their non-zero count, cut to a multiple of 32; the rest follows in decreasing order.  `min_share`: no
+        dense block at all unless those genes hold at least this share of the non-zeros (the ZI / sparse models'
+        'auto': the block pays for them from about half-dense data on)."""
         order = torch.argsort(col_nnz, descending=True, stable=True)
         ok = (col_nnz.to(torch.float64) >= float(density) * max(int(n_total), 1)) & (bad == 0) & (col_nnz > 0)
         ok_sorted = ok[order]
         cand = order[ok_sorted]
         gd = (int(cand.numel()) // 32) * 32
+        if gd and min_share > 0.0:
+            tot = float(col_nnz.sum().item())
+            if tot <= 0.0 or float(col_nnz[cand[:gd]].sum().item()) < float(min_share) * tot:
+                gd = 0
         if gd == 0:
             return order, 0
         keep = torch.ones(order.numel(), dtype=torch.bool, device=order.device)
@@ -224,7 +230,7 @@ class CountTiles:
         return self
 
     @staticmethod
-    def _gene_stats(chunks, m, device, reduce_fn, dense_density, n_total):
+    def _gene_stats(chunks, m, device, reduce_fn, dense_density, n_total, min_share=0.0):
         """Per-gene non-zero counts over all row shards and, for a hybrid layout, the gene order and gd."""
         cn = torch.zeros(m, dtype=torch.int64, device=device)
         bad = torch.zeros(m, dtype=torch.int64, device=device) if dense_density else None
@@ -249,12 +255,12 @@ class CountTiles:
             if reduce_fn is not None:
                 reduce_fn(nt)
             n_total = int(nt.item())
-        order, gd = CountTiles.dense_order(cn, n_total, bad, dense_density)
+        order, gd = CountTiles.dense_order(cn, n_total, bad, dense_density, min_share)
         return cn, order, gd
 
     @classmethod
     def from_dense(cls, X, device='cuda', chunk_bytes=1 << 30, side=None, sort_cols=True, reduce_fn=None,
-                   sort_rows=False, dense_density=None, n_total=None):
+                   sort_rows=False, dense_density=None, n_total=None, dense_min_share=0.0):
         """Pack a dense (n, m) matrix (NumPy or torch, host or device).  `side`: optional dense
         (n, m) float32 DEVICE matrix gathered at the non-zeros (returned as .side_nz, row-side
         slots).  `reduce_fn`: sums the per-gene counts over row shards (all-reduce) so that every
@@ -271,7 +277,7 @@ class CountTiles:
         gd, order = 0, None
         if sort_cols or dense_density:
             cn, order, gd = cls._gene_stats(lambda: (_as_device_chunk(X, r0, min(n, r0 + rows), dev) for r0 in range(0, n, rows)),
-                                            m, dev, reduce_fn, dense_density if side is None else None, n_total)
+                                            m, dev, reduce_fn, dense_density if side is None else None, n_total, dense_min_share)
         self = cls(n, m, device, gd=gd)
         self.dense_density = dense_density if gd else None
         self.sort_rows = bool(sort_rows)
@@ -292,14 +298,14 @@ class CountTiles:
 
     @classmethod
     def from_chunks(cls, n, m, chunk_fn, chunk_rows, device='cuda', sort_cols=True, reduce_fn=None, sort_rows=False,
-                    dense_density=None, n_total=None):
+                    dense_density=None, n_total=None, dense_min_share=0.0):
         """Passes over `chunk_fn(r0, r1) -> dense device tensor` (deterministic generator):
         per-gene counts (when sort_cols), tile counts, fill.  `dense_density`, `n_total`: as from_dense."""
         assert chunk_rows % TILE == 0
         gd, order = 0, None
         if (sort_cols or dense_density) and n > 0 and m > 0:
             cn, order, gd = cls._gene_stats(lambda: (chunk_fn(r0, min(n, r0 + chunk_rows)) for r0 in range(0, n, chunk_rows)),
-                                            m, torch.device(device), reduce_fn, dense_density, n_total)
+                                            m, torch.device(device), reduce_fn, dense_density, n_total, dense_min_share)
         self = cls(n, m, device, gd=gd)
         self.dense_density = dense_density if gd else None
         self.sort_rows = bool(sort_rows)
@@ -315,7 +321,8 @@ class CountTiles:
         return self.finish()
 
     @classmethod
-    def from_scipy(cls, A, device='cuda', chunk_rows=8192, sort_cols=True, reduce_fn=None, dense_density=None, n_total=None):
+    def from_scipy(cls, A, device='cuda', chunk_rows=8192, sort_cols=True, reduce_fn=None, dense_density=None, n_total=None,
+                   dense_min_share=0.0):
         """Pack a SciPy sparse (n, m) count matrix: row chunks of the CSR form are expanded on the
         device (chunk_rows x m floats at a time), so neither host nor device ever holds the dense
         matrix (real single-cell matrices are > 90 % zeros; reference cmatrix.py:39-53 only offers
@@ -342,7 +349,7 @@ class CountTiles:
             self.finish_count()
             return self.finish()
         return cls.from_chunks(n, m, chunk_fn, max(TILE, chunk_rows // TILE * TILE), dev, sort_cols=sort_cols,
-                               reduce_fn=reduce_fn, dense_density=dense_density, n_total=n_total)
+                               reduce_fn=reduce_fn, dense_density=dense_density, n_total=n_total, dense_min_share=dense_min_share)
 
     @property
     def c_struct(self):

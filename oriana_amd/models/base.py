@@ -66,7 +66,8 @@ class FactorModel:
         float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip).  Every model takes it:
         inside the ZI models D_hat = 1 at every non-zero count, so their nest is the pCMF nest plus the D_hat[i, k] weight
         on the gene side; the sparse models' den runs against the masked FV image, their accumulation against FV * S_hat,
-        their log sums through a second gene-side pass.
+        their log sums through a second gene-side pass.  ``'auto'`` for the ZI / sparse models: the same threshold, but only
+        when the genes above it hold at least 75 % of the non-zeros (i.e. on data that are about half dense or denser).
         ``'auto'``: engine.auto_dense_density -- engine.DENSE_DENSITY_DEFAULT (or the environment's ORIANA_DENSE_DENSITY;
         ``0`` / ``off`` disables) for matrices of at least 2e8 entries and a K the dense kernels are compiled for; ignored
         for a prebuilt ``engine.CountTiles`` (its own layout is used).
@@ -101,13 +102,15 @@ class FactorModel:
         elif _is_sparse_input(cmatrix):
             A = cmatrix._sparse if hasattr(cmatrix, '_sparse') else cmatrix
             X_host = A                     # the host-side initialisation reads it in sparse form
-            self.counts = engine.CountTiles.from_scipy(A, self.device, reduce_fn=rf, dense_density=dd, n_total=n_total)
+            self.counts = engine.CountTiles.from_scipy(A, self.device, reduce_fn=rf, dense_density=dd, n_total=n_total,
+                                                       dense_min_share=getattr(self, '_dense_min_share', 0.0))
         else:
             X = cmatrix.as_array() if hasattr(cmatrix, 'as_array') else cmatrix
             if not isinstance(X, torch.Tensor):
                 X = np.asarray(X)
                 X_host = X
-            self.counts = engine.CountTiles.from_dense(X, self.device, reduce_fn=rf, dense_density=dd, n_total=n_total)
+            self.counts = engine.CountTiles.from_dense(X, self.device, reduce_fn=rf, dense_density=dd, n_total=n_total,
+                                                       dense_min_share=getattr(self, '_dense_min_share', 0.0))
         self.n = self.counts.n
         self.m = self.p = self.counts.m
         self.n_total = int(n_total) if n_total is not None else odist.sum_int(self.n, process_group, self.device)
@@ -166,10 +169,11 @@ class FactorModel:
         """The density threshold of the hybrid layout for this model, or None."""
         if isinstance(cmatrix, engine.CountTiles):
             return None
-        if (self.zi or self.sparse) and isinstance(dense_density, str):
-            # the ZI / sparse models take the hybrid layout on request only ('auto' keeps them sliced: at the benchmark's
-            # 90 % zeros the dense block is neutral for them -- profiles/r04_zigap_hybrid_ab.json -- and pays from ~50 % on)
-            return None
+        # 'auto' for the ZI / sparse models: the dense block is neutral for them at the benchmark's 90 % zeros and pays
+        # 1.4-2 x at the reference generator's own ~50 % (profiles/r04_zigap_hybrid_ab.json, r04_sparsegap_hybrid_ab.json), so
+        # they take it only when the genes above the threshold hold most of the non-zeros (decided at packing, from the
+        # per-gene counts: CountTiles.dense_order min_share)
+        self._dense_min_share = 0.75 if ((self.zi or self.sparse) and isinstance(dense_density, str)) else 0.0
         if isinstance(init, str) and init == 'nmf':      # the on-device NMF start walks the sliced layout only
             return None
         shape = getattr(cmatrix, 'shape', None)

@@ -145,6 +145,12 @@ def test_hybrid_gene_order_rules():
     # empty genes never qualify, whatever the threshold
     order1, gd1 = CountTiles.dense_order(torch.zeros(64, dtype=torch.int64), n, torch.zeros(64, dtype=torch.int64), 0.0)
     assert gd1 == 0 and sorted(order1.tolist()) == list(range(64))
+    # min_share (the ZI / sparse models' 'auto'): the dense block only when its genes hold that share of the non-zeros
+    share = float(nnz[head].sum()) / float(nnz.sum())
+    o2, g2 = CountTiles.dense_order(nnz, n, bad, 0.5, min_share=share - 0.01)
+    assert g2 == gd and torch.equal(o2, order)
+    o3, g3 = CountTiles.dense_order(nnz, n, bad, 0.5, min_share=share + 0.01)
+    assert g3 == 0 and torch.equal(o3, order0)
 
 
 def test_hybrid_auto_threshold(monkeypatch):

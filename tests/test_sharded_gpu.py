@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, path, name, out):
+def _worker(rank, world, port, path, name, out, dense_density=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -37,7 +37,9 @@ def _worker(rank, world, port, path, name, out):
         r0, r1 = odist.shard_rows(X.shape[0], rank, world)
         dev = torch.device('cuda', 0)
         # every rank packs the genes in the same order: the per-gene counts are all-reduced
-        counts = engine.CountTiles.from_dense(X[r0:r1], dev, reduce_fn=lambda t: odist.all_reduce_sum(t))
+        counts = engine.CountTiles.from_dense(X[r0:r1], dev, reduce_fn=lambda t: odist.all_reduce_sum(t),
+                                              dense_density=dense_density, n_total=X.shape[0])
+        assert (counts.gd >= 32) == bool(dense_density)
         cls = getattr(M, name)
         model = cls(counts, k=K, tau=float(g['meta/tau']), init=(g['s0/a1'][r0:r1], g['s0/b1']), device=dev,
                     process_group=dist.group.WORLD)
@@ -91,6 +93,31 @@ def test_two_ranks_match_one(tmp_path, name, fn):
         tol = 1e-3 if k in ('p_d', 'p_s', 'pi_d', 'pi_s') else 2e-5
         assert err_colrel(got[k], ref[k]) < tol, k
     # the deviances / Frobenius norm are sums over the row shards, all-reduced
+    ref_m = np.array([single.reconstruction_deviance(), single.explained_deviance(), single.frobenius_norm()])
+    np.testing.assert_allclose(got['metrics'], ref_m, rtol=1e-4)
+
+
+@pytest.mark.parametrize('name,fn', [('ZIGaP', 'zigap_odd_rand.npz'), ('SparseGaP', 'sparsegap_odd_rand.npz'),
+                                     ('SparseZIGaP', 'sparsezigap_c1_rand.npz')])
+def test_two_ranks_hybrid_layout_zi_and_sparse(tmp_path, name, fn):
+    """The ZI / sparse models row-sharded over two ranks ON THE HYBRID LAYOUT (every gene expressed in >= 10 % of all cells
+    dense, the same gene order and dense set on both ranks from the all-reduced counts): the single-process run on the
+    sliced layout is reproduced to summation order."""
+    import oriana_amd.models as M
+    path = golden_files(fn)[0]
+    out = str(tmp_path / 'sharded_hybrid.npz')
+    mp.spawn(_worker, args=(2, _free_port(), path, name, out, 0.1), nprocs=2, join=True)
+    got = np.load(out)
+    g = load_golden(path)
+    single = getattr(M, name)(g['X'], k=int(g['meta/k']), tau=float(g['meta/tau']), init=(g['s0/a1'], g['s0/b1']))
+    assert single.counts.gd == 0
+    single.fit(2)
+    ref = single.state()
+    for k in got.files:
+        if k == 'metrics':
+            continue
+        tol = 1e-3 if k in ('p_d', 'p_s', 'pi_d', 'pi_s') else 2e-5
+        assert err_colrel(got[k], ref[k]) < tol, k
     ref_m = np.array([single.reconstruction_deviance(), single.explained_deviance(), single.frobenius_norm()])
     np.testing.assert_allclose(got['metrics'], ref_m, rtol=1e-4)
 

@@ -151,6 +151,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
 
     f16v rs[NT];                         // R of the strip: [cell acc_row(v, h)][factor 32 nt + c]
     f4v rt = {0.f, 0.f, 0.f, 0.f};       // tail factors: 4 x 4 blocks (cells x factors), this half's genes
+#ifdef ORIANA_DN_ABL_RT4
+    f4v rt4[4] = {rt, rt, rt, rt};
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -218,6 +221,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         // ================= stage A: the matrix instructions of D(gt + 1), one per slot; beside them S(gt), the splits of
         // s and R's tail products
         bool allok = true;
+#ifdef ORIANA_DN_ABL_VAND
+        uint32_t okbits = 0xFFFFFFFFu;
+#endif
 #ifdef ORIANA_DN_ABL_PKMUL
         float pk_x = 0.f, pk_r = 0.f; bool pk_ok = true;
 #endif
@@ -261,7 +267,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     const uint32_t xi = (v & 1) ? (wd >> 16) : (wd & 0xFFFFu);
                     const float den = l0[v];
                     const bool ok = den >= DEN_MIN;                        // false for 0, tiny and NaN
-#ifndef ORIANA_DN_ABL_NOAND
+#ifdef ORIANA_DN_ABL_VAND
+                    okbits &= ok ? 0xFFFFFFFFu : 0u;               /* analysis switch: the running test on the vector ALU */
+#elif !defined(ORIANA_DN_ABL_NOAND)
                     allok = allok && ok;
 #endif
                     // branch-free: a failed test leaves the NaN sentinel in the stored tile (also where x == 0: the
@@ -311,6 +319,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     for (int q = 0; q < 4; ++q) reinterpret_cast<f4v *>(sblk)[q * 64 + lane] = tq[q];
                     // one flag per (cell tile, gene tile): lane (t mod 64) keeps bit t / 64 of its tile t = gt - gt0 and
                     // the flags leave after the loop (no store, no branch here)
+#ifdef ORIANA_DN_ABL_VAND
+                    allok = okbits != 0u;
+#endif
                     fl |= (__any(!allok) && lane == ((gt - gt0) & 63)) ? (1u << ((gt - gt0) >> 6)) : 0u;
 #else
                     if (tq[0].x == 12345.f && __any(!allok)) reinterpret_cast<f4v *>(sblk)[lane] = tq[1] + tq[2] + tq[3];
@@ -329,7 +340,11 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                         // 4 (b % 8) + i (this lane's value), B[b][j] = FV[gene][KM + j]: exact float32 FMAs on the matrix pipe
                         // (the B operands of four values at a time: 4 registers in flight instead of 16)
                         if ((vv & 3) == 0) t2 = tails[32 + (h * 4 + (lane & 3)) * 4 + (vv >> 2)];
+#ifdef ORIANA_DN_ABL_RT4
+                        rt4[vv & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, t2[vv & 3], rt4[vv & 3], 0, 0, 0);   /* analysis switch */
+#else
                         rt = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, t2[vv & 3], rt, 0, 0, 0);
+#endif
                     }
                     if ((vv & 1) == 0) { sh = b0; sm = c0; sl = __float_as_uint(s0); }
                     else {
@@ -428,6 +443,9 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
             }
         }
     if (TAIL) {
+#ifdef ORIANA_DN_ABL_RT4
+        rt = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
+#endif
         // lane 4 b + j holds, in register e, the tail sum of cell 4 (b % 8) + e and factor KM + j over its half's genes
         rt.x += __shfl_xor(rt.x, 32, 64); rt.y += __shfl_xor(rt.y, 32, 64);
         rt.z += __shfl_xor(rt.z, 32, 64); rt.w += __shfl_xor(rt.w, 32, 64);

@@ -1,0 +1,69 @@
+# -*- coding: utf-8 -*-
+"""Files the counter passes of tools/evidence_r04_pmc.sh (gpurun_out/r04/r04_<workload>_{sq1,sq2,fetch,write}.json) under
+profiles/: r04_sq_secondary.json (what binds the kernels of configs[2] / configs[4]) and r04_pmc_hbm_<workload>.json (HBM
+traffic per sweep, with the guide's gfx950 correction spelled out per kernel) -- the `roofline.traffic` of those workloads."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = os.path.join(ROOT, 'gpurun_out', 'r04') + '/'
+P = os.path.join(ROOT, 'profiles') + '/'
+KiB = 1024.0
+ALG = {'c3_zi': 16.0 * 100000 * 20000 + 4.0 * 50 * (2 * 100000 + 2 * 20000) + 4.0 * 50 * 20000,
+       'c5_sparse': 4.0 * 500000 * 25000 + 4.0 * 64 * (2 * 500000 + 2 * 25000) + 12.0 * 64 * 25000}
+# kernels whose reads are wide coalesced streams (16 B per lane, global_load or LDS-DMA): FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM)
+WIDE = ('k_row_pass', 'k_dt_times_factor', 'k_zi_row', 'k_zi_col', 'k_dropout_sweep')
+SKIP = ('k_dropout_fused', 'k_dropout_fix_nz')         # the float64 A/B leg of bench.py and the one-time initialisation: not part of a sweep
+
+sq_all = {}
+for w in ('c3_zi', 'c5_sparse'):
+    try:
+        s1 = json.load(open(F + 'r04_%s_sq1.json' % w))['per_dispatch_mean']
+        s2 = json.load(open(F + 'r04_%s_sq2.json' % w))['per_dispatch_mean']
+        fe = json.load(open(F + 'r04_%s_fetch.json' % w))['per_dispatch_mean']
+        wr = json.load(open(F + 'r04_%s_write.json' % w))['per_dispatch_mean']
+    except FileNotFoundError:
+        continue
+    der = {}
+    for k in s1:
+        if any(x in k for x in SKIP) or k not in s2:
+            continue
+        n = dict(s1[k]); n.update(s2[k])
+        clk = n['GRBM_GUI_ACTIVE'] / 8.0
+        e = {'kernel_cycles': clk, 'valu_busy_fraction': n['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / clk,
+             'wave_cycles_waiting': n['SQ_WAIT_ANY'] / n['SQ_WAVE_CYCLES'],
+             'wave_cycles_issue_stalled': n['SQ_WAIT_INST_ANY'] / n['SQ_WAVE_CYCLES'],
+             'wave_cycles_issuing': n['SQ_ACTIVE_INST_ANY'] / n['SQ_WAVE_CYCLES'],
+             'lds_bank_conflict_fraction': n['SQ_LDS_BANK_CONFLICT'] / max(n['SQ_LDS_IDX_ACTIVE'], 1.0),
+             'valu_instructions': n['SQ_INSTS_VALU'], 'lds_instructions': n['SQ_INSTS_LDS']}
+        if n.get('SQ_INSTS_MFMA'):
+            e['matrix_pipe_busy_fraction'] = n['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / clk
+            e['valu_instructions_per_matrix_instruction'] = n['SQ_INSTS_VALU'] / n['SQ_INSTS_MFMA']
+        der[k] = e
+    sq_all[w] = der
+    tr, raw = {}, {}
+    for k in fe:
+        if any(x in k for x in SKIP):
+            continue
+        f = fe[k].get('FETCH_SIZE', 0.0)
+        wv = wr.get(k, {}).get('WRITE_SIZE', 0.0)
+        raw[k] = {'FETCH_SIZE': f, 'WRITE_SIZE': wv}
+        tr[k] = ((2.0 if any(x in k for x in WIDE) else 1.0) * f + wv) * KiB
+    tr['total'] = sum(tr.values())
+    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload %s --steps 3 --warmup 1 --no-cpu '
+                          '(and a second, separate pass with --pmc WRITE_SIZE); tools/evidence_r04_pmc.sh' % w,
+               'workload': w, 'n_gpus': 1, 'unit': 'KB per launch (one launch of each kernel per sweep), as rocprofv3 reports them',
+               'counters': raw,
+               'corrections': 'MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read.  Doubled: '
+                              + ', '.join(WIDE) + ' (16-byte per-lane record / D_hat streams, LDS-DMA).  The column passes read 8-byte + 2-byte per-lane '
+                              'streams plus factor tiles served by L2 / Infinity Cache: taken as counted.  WRITE_SIZE as counted; KB taken as KiB.  Left out: '
+                              + ', '.join(SKIP) + ' (the float64 A/B leg of the bench line and the one-time initialisation).',
+               'traffic_bytes_per_pass': tr, 'algorithmic_bytes': ALG[w]}, open(P + 'r04_pmc_hbm_%s.json' % w, 'w'), indent=1)
+    print(w, 'traffic per sweep %.1f GB against %.1f GB algorithmic' % (tr['total'] / 1e9, ALG[w] / 1e9), {k[:28]: round(v / 1e9, 2) for k, v in tr.items()})
+json.dump({'command': 'tools/evidence_r04_pmc.sh: two rocprofv3 --pmc passes per workload (8 SQ counters + GRBM_GUI_ACTIVE; counters only with --kernel-trace) over '
+                      'python3 bench.py --workload {c3_zi, c5_sparse} --steps 3 --warmup 1 --no-cpu',
+           'unit': 'per launch; wave-cycle shares of SQ_WAVE_CYCLES; busy fractions of the kernel\'s cycles x 1024 SIMDs',
+           'derived': sq_all}, open(P + 'r04_sq_secondary.json', 'w'), indent=1)
+for w, der in sq_all.items():
+    for k, e in der.items():
+        print(w, k[:40], {a: round(b, 3) for a, b in e.items() if 'fraction' in a or 'wave_cycles' in a})

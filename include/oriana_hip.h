@@ -171,7 +171,10 @@ int oriana_row_pass(const oriana_counts *cm,
  * `gene_splits` work-groups: a row block is one work-group, so a matrix of 10,000 cells (configs[1]) ran the pass on 40
  * of the 256 CUs.  R is then (gene_splits, n, Kp): every group stores the row sums of its gene range in its own slab
  * (no atomics, nothing to clear); oriana_finalize_slabs / oriana_gamma_update_finalize add the slabs up.
- * oriana_row_pass_gene_splits: the split that fills the chip (1 from 256 row-side work-groups on). */
+ * oriana_row_pass_gene_splits: the split that fills the chip -- below 256 row-side work-groups, and [r4] between one and
+ * eight rounds of the chip for the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100), where the last, partly
+ * filled round costs up to a third of the pass (391 row blocks = configs[2]: 2.11 -> 1.81 ms with three gene ranges);
+ * ORIANA_ROW_SPLIT_ROUNDS=off keeps round 3's rule. */
 int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t K);
 int oriana_row_pass_split(const oriana_counts *cm, const float *FU, const float *FV, float *R, float *s_cs,
                           int32_t *tile_flag, int64_t K, int64_t gene_splits, void *stream);
@@ -184,6 +187,13 @@ int oriana_row_pass_split(const oriana_counts *cm, const float *FU, const float 
 int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
                            const float *w_nz, float *R, float *s_cs, float *sw_cs, int32_t *tile_flag, int64_t K,
                            void *stream);
+
+/* [r4] Every variant of the row pass behind one entry: oriana_row_pass (FV2 = NULL) or oriana_row_pass_masked (FV2 given,
+ * s_rs must be NULL; ORIANA_EKRANGE where the two images do not fit) with the gene-tile split of oriana_row_pass_split:
+ * R = (gene_splits, n, Kp), one slab per gene range (s_rs given: R untouched). */
+int oriana_row_pass_general(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
+                            const float *w_nz, float *R, float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag,
+                            int64_t K, int64_t gene_splits, void *stream);
 
 /* R[i,:] = sum_j w_ij s_ij FV[j,:] with s given in row-side slots (sparse models: S_hat-weighted sums). */
 int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz,

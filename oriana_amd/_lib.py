@@ -51,6 +51,7 @@ _SIGS = {
     'oriana_row_pass_split': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
     'oriana_row_pass_masked': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'oriana_row_pass_general': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_det_scratch_bytes': (c_int64, [_I, _I]),

@@ -2161,7 +2161,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
         constexpr int KP = 4 * G * T4 + G * TAIL;
         const size_t lb2 = 2 * lds_bytes(G, T4, TAIL);
         if (use_k100(G, T4) || pick_nsub(KP) != 1 || lb2 > (size_t)LDS_BUDGET) return ORIANA_EKRANGE;
-        const dim3 grid2((unsigned)(cm->nrb * WaveGeo<G>::SPLIT)), block2(1024);
+        const dim3 grid2((unsigned)(cm->nrb * WaveGeo<G>::SPLIT), (unsigned)gene_splits), block2(1024);
         if (w_nz) {
             rc = set_lds(k_row_pass<G, T4, TAIL, 6>, lb2);
             if (rc) return rc;
@@ -2452,7 +2452,27 @@ extern "C" int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t 
     if (!cm || !pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 1;
     const int64_t groups = cm->nrb * ((use_k100(cfg.G, cfg.T4) || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (256 / (16 * (64 / cfg.G))));
     static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
-    if (groups >= 256 && forced <= 0) return 1;
+    if (groups >= 256 && forced <= 0) {
+        // Between one and eight rounds of the chip the two-lane kernels (one 512-thread group per CU: the image and the
+        // registers leave room for one) lose up to a third of the time to the last, partly filled round -- 391 row blocks
+        // (configs[2]) run as two rounds.  A split into sp gene ranges makes the rounds sp times shorter: cost
+        // ceil(groups * sp / 256) / sp rounds, + 2 % per extra range for its restaging; taken from a predicted 8 % on.
+        // Measured (tools/perf_row_splits.py): 100,000 x 20,000, K = 50: 2.11 -> 1.81 ms (sp = 3); 150,000 x 25,000,
+        // K = 64: 4.11 -> 3.32 ms (sp = 5); 125,000 x 30,000, K = 100 (1.91 rounds): 4.59 -> 4.72 ms, hence the model.
+        const bool one_group_per_cu = use_k100(cfg.G, cfg.T4) || (k64_kernels() && k64_cfg(cfg.G, cfg.T4, cfg.TAIL));
+        static const bool rounds_off = [] { const char *e = getenv("ORIANA_ROW_SPLIT_ROUNDS"); return e && !strcmp(e, "off"); }();
+        if (!one_group_per_cu || groups >= 8 * 256 || rounds_off) return 1;
+        double best = (double)((groups + 255) / 256);
+        const double base = best;
+        int64_t best_sp = 1;
+        for (int64_t sp = 2; sp <= 8 && sp <= cm->ncb; ++sp) {
+            const double c = (double)((groups * sp + 255) / 256) / (double)sp * (1.0 + 0.02 * (double)(sp - 1));
+            if (c < 0.98 * best) { best = c; best_sp = sp; }          // (a finer split has to earn its slabs)
+        }
+        if (best > 0.92 * base) return 1;
+        const int64_t per = (cm->ncb + best_sp - 1) / best_sp;
+        return (cm->ncb + per - 1) / per;
+    }
     // two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20: 77 / 42 / 25 / 24 us
     // for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
     int64_t sp = forced > 0 ? forced : 512 / groups;
@@ -2489,6 +2509,26 @@ extern "C" int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, 
     if (cm->m == 0) return oriana_row_pass(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, K, stream);
     hipStream_t s = (hipStream_t)stream;
 #define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, s, FV2)
+    ORIANA_FOR_CFG(cfg, CALL);
+#undef CALL
+    return 0;
+}
+
+// The row pass in full generality: every variant of oriana_row_pass / oriana_row_pass_masked (FV2 may be null) with the gene
+// tiles of a row block split over gene_splits work-groups, each storing its row sums in its own slab of R.
+extern "C" int oriana_row_pass_general(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
+                                       const float *w_nz, float *R, float *s_cs, float *sw_cs, float *s_rs,
+                                       int32_t *tile_flag, int64_t K, int64_t gene_splits, void *stream) {
+    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
+    KCfg cfg;
+    if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
+    if (cm->n == 0) return 0;
+    if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
+    if ((w_nz != nullptr) != (sw_cs != nullptr) || (FV2 && s_rs)) return ORIANA_EINVAL;
+    if (gene_splits < 1 || gene_splits > 65535 || (cm->ncb > 0 && gene_splits > cm->ncb)) return ORIANA_EINVAL;
+    if (cm->m == 0) FV2 = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s, FV2, (int)gene_splits)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;

@@ -803,23 +803,27 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
         # pass leaves s in row-side slots and a second row product follows.
         fused = False
         F2 = None
+        gs = ws.row_gene_splits                     # gene ranges per row block (slabs of R), see oriana_row_pass_gene_splits
+        nslab = 1
         if sparse:
             F2 = ws.extra('FVS', m)
             call('oriana_scale_factor', ptr(F2), ptr(ws.FV), ptr(S_hat), ptr(ct.col_perm), m, K, 0, st)
         if have_sliced:
             if sparse and _FUSE_SPARSE_ROWS:
                 with _span(ws, 'row_pass'):
-                    rc = _lib.load().oriana_row_pass_masked(cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(F2) + goff, ptr(w_nz), ptr(ws.R),
-                                                            ptr(ws.s_cs), ptr(sw_cs), ptr(ws.tile_flag), K, st)
+                    rc = _lib.load().oriana_row_pass_general(cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(F2) + goff, ptr(w_nz), ptr(ws.R),
+                                                             ptr(ws.s_cs), ptr(sw_cs), None, ptr(ws.tile_flag), K, gs, st)
                 if rc not in (0, -2):
-                    raise _lib.OrianaHipError('oriana_row_pass_masked failed with code %d' % rc)
+                    raise _lib.OrianaHipError('oriana_row_pass_general failed with code %d' % rc)
                 fused = rc == 0
             if not fused:
                 if sparse and ws.s_rs is None:   # row-side copy of s for the second row product (lazy: the fused form never needs it)
                     ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
                 with _span(ws, 'row_pass'):
-                    call('oriana_row_pass', cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(w_nz), ptr(ws.R), ptr(ws.s_cs), ptr(sw_cs),
-                         ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, st)
+                    call('oriana_row_pass_general', cst, ptr(ws.FU), ptr(ws.FV) + goff, None, ptr(w_nz), ptr(ws.R), ptr(ws.s_cs),
+                         ptr(sw_cs), ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, gs, st)
+            if fused or not sparse:
+                nslab = gs                       # (the second row product of the unfused sparse form writes one slab)
             with _span(ws, 'fixup'):
                 call('oriana_fixup', cst, ptr(ws.tile_flag), ptr(ws.s_cs), ptr(sw_cs),
                      ptr(ws.s_rs) if (sparse and not fused) else None,
@@ -838,7 +842,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             with _span(ws, 'fixup'):
                 call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
                      ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, 0, st)
-        call('oriana_finalize', ptr(Z_i), ptr(ws.FU), ptr(ws.R), None, ptr(ct.row_perm), n, K, 1, st)
+        call('oriana_finalize_slabs', ptr(Z_i), ptr(ws.FU), ptr(ws.R), nslab, ptr(ct.row_perm), n, K, st)
         if Z_log is not None:
             # E[log U]-weighted row factor of the log sums: built NOW, from the pre-update E[log U] (the caller
             # may run the cell-side update between the two phases)

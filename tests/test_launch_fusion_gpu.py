@@ -129,6 +129,57 @@ def test_gene_split_rule(eng):
     import scipy.sparse as sp
     tall = eng.CountTiles.from_scipy(sp.random(70000, 600, density=0.01, format='csr', random_state=2, dtype=np.float32), 'cuda')
     assert tall.nrb >= 256 and eng.ZWorkspace(tall, 20).row_gene_splits == 1
+    # [r4] between one and eight rounds of the chip the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100) split by
+    # the round model: 391 row blocks are two rounds (three gene ranges: 5 / 3), 489 row blocks are two rounds whatever the split
+    import os
+    if os.environ.get('ORIANA_ROW_SPLIT_ROUNDS') != 'off' and not os.environ.get('ORIANA_PASS_IMPL'):
+        c3 = eng.CountTiles.from_scipy(sp.random(100000, 1200, density=0.004, format='csr', random_state=3, dtype=np.float32), 'cuda')
+        assert c3.nrb == 391 and c3.ncb == 5
+        assert eng.ZWorkspace(c3, 50).row_gene_splits == 3 and eng.ZWorkspace(c3, 100).row_gene_splits == 3
+        assert eng.ZWorkspace(c3, 20).row_gene_splits == 1                       # (narrow kernels: several groups per CU)
+        c8 = eng.CountTiles.from_scipy(sp.random(125000, 1200, density=0.004, format='csr', random_state=4, dtype=np.float32), 'cuda')
+        assert c8.nrb == 489 and eng.ZWorkspace(c8, 100).row_gene_splits == 1
+
+
+@pytest.mark.parametrize('K', [20, 50, 64, 100])
+@pytest.mark.parametrize('nest', ['zi', 'zi_quirk', 'sparse', 'sparse_zi', 'weights'])
+def test_zq_with_gene_splits_matches_one_group_per_row_block(eng, K, nest):
+    """[r4] engine.zq hands every variant of the row pass (plain, D_hat[i, k] quirk, per-entry weights, fused and unfused sparse
+    forms) the gene-tile split of its workspace: against a workspace forced to one group per row block, float32 rounding apart."""
+    rng = np.random.default_rng(K + len(nest))
+    n, m = 530, 900
+    X = _counts(rng, n, m, 0.15)
+    lu = torch.from_numpy(rng.normal(size=(n, K)).astype(np.float32)).cuda()
+    lv = torch.from_numpy((rng.normal(size=(m, K)) - 0.5).astype(np.float32)).cuda()
+    ps = rng.random((m, K))
+    kw = {}
+    if nest.startswith('sparse'):
+        kw['S_tilde'] = torch.from_numpy((ps > 0.3).astype(np.float32)).cuda()
+        kw['S_hat'] = torch.from_numpy(ps.astype(np.float32)).cuda()
+    if nest in ('zi_quirk', 'sparse_zi'):
+        kw['dq'] = torch.rand(n, K, device='cuda')
+    side = None
+    if nest == 'weights':
+        side = torch.from_numpy(rng.random((n, m)).astype(np.float32)).cuda()
+    ct = eng.CountTiles.from_dense(X, 'cuda', side=side)
+    if nest == 'weights':
+        kw['w_nz'] = ct.side_nz
+
+    def run(splits):
+        ws = eng.ZWorkspace(ct, K, need_sw=nest == 'weights')
+        if splits is not None:
+            ws.row_gene_splits = splits
+            ws.R = torch.zeros(splits, n, ws.Kp, device='cuda') if splits > 1 else torch.zeros(n, ws.Kp, device='cuda')
+        o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+        eng.zq(ws, o[0], o[1], o[2] if nest != 'weights' else None, lu, lv, **kw)
+        torch.cuda.synchronize()
+        return o[:2] + ([o[2]] if nest != 'weights' else [])
+    ref = run(1)
+    for splits in (2, ct.ncb):
+        got = run(splits)
+        for a, b in zip(got, ref):
+            sc = b.abs().max(0, keepdim=True).values.clamp_min(1e-30)
+            assert float(((a - b).abs() / (b.abs() + sc)).max()) < 3e-6, (splits, nest)
 
 
 @pytest.mark.parametrize('r,K,perm,nslab', [(1000, 20, True, 1), (257, 100, False, 1), (3, 5, True, 3), (5000, 7, True, 4),

@@ -188,12 +188,31 @@ int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, const float
                            const float *w_nz, float *R, float *s_cs, float *sw_cs, int32_t *tile_flag, int64_t K,
                            void *stream);
 
+/* [r4] Which work-groups of the row pass share a row block.  The two-lane kernels (33 <= Kp <= 64, 85 <= K <= 100) run one
+ * 512-thread group per CU, so the pass advances in ROUNDS of 256 row blocks and the last, partly filled round costs a whole
+ * one (measured at 1M x 30k, K = 100: 3840 / 3907 / 4096 row blocks = 33.9 / 35.8 / 36.2 ms).  The row blocks [0, nfull) --
+ * the full rounds -- are one work-group each (all gene tiles, row sums in slab 0 of R); every row block from nfull on is
+ * `parts` work-groups: part p takes the gene tiles [edge[p], edge[p+1]) and stores its row sums in slab p, so the last round
+ * is made of shorter groups.  nfull = 0 is the split of oriana_row_pass_split (short matrices); nfull = nrb, parts = 1 no
+ * split at all.  R = (parts, n, Kp); the rows below 256 * nfull have slab 0 only (oriana_finalize_slabs_from). */
+typedef struct oriana_row_split {
+    int32_t nfull;
+    int32_t parts;          /* 1 .. 8 */
+    int32_t edge[9];        /* edge[0] = 0 <= ... <= edge[parts] = ncb */
+} oriana_row_split;
+
+/* The split that fills the chip for this matrix and K (what oriana_row_pass_gene_splits decided alone in round 3).
+ * tile_cost: HOST array of ncb relative costs of the gene tiles (the ranges are cut at equal-cost points; genes are packed
+ * by decreasing density, so equal tile counts are not equal work) or NULL = equal.  ORIANA_ROW_SPLIT_ROUNDS=off: only the
+ * short-matrix rule. */
+int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const double *tile_cost, oriana_row_split *out);
+
 /* [r4] Every variant of the row pass behind one entry: oriana_row_pass (FV2 = NULL) or oriana_row_pass_masked (FV2 given,
- * s_rs must be NULL; ORIANA_EKRANGE where the two images do not fit) with the gene-tile split of oriana_row_pass_split:
- * R = (gene_splits, n, Kp), one slab per gene range (s_rs given: R untouched). */
+ * s_rs must be NULL; ORIANA_EKRANGE where the two images do not fit) under a split (NULL = none); s_rs given: R untouched.
+ * Kernels other than the two-lane ones take nfull = 0 only (ORIANA_EINVAL otherwise) and cut their ranges evenly. */
 int oriana_row_pass_general(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
                             const float *w_nz, float *R, float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag,
-                            int64_t K, int64_t gene_splits, void *stream);
+                            int64_t K, const oriana_row_split *split, void *stream);
 
 /* R[i,:] = sum_j w_ij s_ij FV[j,:] with s given in row-side slots (sparse models: S_hat-weighted sums). */
 int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz,
@@ -303,6 +322,9 @@ int oriana_finalize(float *Z, const float *F, const float *R, const float *mul, 
 /* Z[o,k] += F[i,k] * (R[0][i,k] + ... + R[nslab-1][i,k]) -- R = (nslab, r, Kp) as oriana_row_pass_split leaves it. */
 int oriana_finalize_slabs(float *Z, const float *F, const float *R, int64_t nslab, const int32_t *row_index,
                           int64_t r, int64_t K, void *stream);
+/* [r4] the same where only the rows from slab_row0 on have more than slab 0 (oriana_row_split: slab_row0 = 256 * nfull). */
+int oriana_finalize_slabs_from(float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
+                          int64_t r, int64_t K, void *stream);
 
 /* Slow path (exact reference arithmetic) for the entries flagged by oriana_row_pass.
  * variant bit 0: S_tilde / S_hat present (sparse models); bit 1: D_hat weights (w_nz);
@@ -395,6 +417,12 @@ int oriana_gamma_update_finalize(double *a1, double *a2, double *E, float *Elog,
                                  double *colsum_E, double *colsum_Elog,
                                  const double *prior1, const double *prior2,
                                  float *Z, const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                                 const double *rate_vec, int64_t r, int64_t K, void *stream);
+/* [r4] ... with oriana_finalize_slabs_from's slab_row0. */
+int oriana_gamma_update_finalize_from(double *a1, double *a2, double *E, float *Elog,
+                                 double *colsum_E, double *colsum_Elog,
+                                 const double *prior1, const double *prior2,
+                                 float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
                                  const double *rate_vec, int64_t r, int64_t K, void *stream);
 
 /* M-step for one Gamma node (gap.py:117-129; utils.py:39-51):

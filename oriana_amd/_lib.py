@@ -29,6 +29,11 @@ class OrianaDense(ctypes.Structure):
     _fields_ = [('n', c_int64), ('gd', c_int64), ('nct', c_int64), ('x', c_void_p)]
 
 
+class OrianaRowSplit(ctypes.Structure):
+    """struct oriana_row_split (include/oriana_hip.h): which work-groups of the row pass share a row block."""
+    _fields_ = [('nfull', ctypes.c_int32), ('parts', ctypes.c_int32), ('edge', ctypes.c_int32 * 9)]
+
+
 class OrianaClearList(ctypes.Structure):
     """struct oriana_clear_list (include/oriana_hip.h): up to 8 buffers zero-filled by the factor preparation's launch."""
     _fields_ = [('ptr', c_void_p * 8), ('bytes', c_int64 * 8)]
@@ -51,7 +56,8 @@ _SIGS = {
     'oriana_row_pass_split': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
     'oriana_row_pass_masked': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    'oriana_row_pass_general': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_row_pass_general': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, ctypes.POINTER(OrianaRowSplit), _P]),
+    'oriana_row_pass_plan': (c_int, [ctypes.POINTER(OrianaCounts), _I, _P, ctypes.POINTER(OrianaRowSplit)]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_det_scratch_bytes': (c_int64, [_I, _I]),
@@ -70,6 +76,7 @@ _SIGS = {
     'oriana_dense_fix_nz': (c_int, [ctypes.POINTER(OrianaDense), _P, _I, _P, _P, c_double, _P]),
     'oriana_finalize': (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, _P]),
     'oriana_finalize_slabs': (c_int, [_P, _P, _P, _I, _P, _I, _I, _P]),
+    'oriana_finalize_slabs_from': (c_int, [_P, _P, _P, _I, _I, _P, _I, _I, _P]),
     'oriana_fixup': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                              _I, c_int, _P]),
     'oriana_zq_workspace_bytes': (c_int64, [_I, _I, _I, _I]),
@@ -80,6 +87,7 @@ _SIGS = {
     'oriana_gamma_update': (c_int, [_P] * 13 + [_I, _I, _P]),
     'oriana_mstep_gamma': (c_int, [_P, _P, _P, _P, c_double, _I, _P]),
     'oriana_gamma_update_finalize': (c_int, [_P] * 11 + [_I, _P, _P, _I, _I, _P]),
+    'oriana_gamma_update_finalize_from': (c_int, [_P] * 11 + [_I, _I, _P, _P, _I, _I, _P]),
     'oriana_mstep_gamma_pair': (c_int, [_P, _P, _P, _P, c_double, _P, _P, _P, _P, c_double, _P, _I, _P]),
     'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),
     'oriana_dropout_update': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

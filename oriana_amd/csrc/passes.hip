@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(float *__restrict__ C, const
 __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const float *__restrict__ F,
                                                   const float *__restrict__ R, const float *__restrict__ mul,
                                                   const int32_t *__restrict__ row_index, int64_t r, int K, int Kp,
-                                                  int accumulate, int nslab) {
+                                                  int accumulate, int nslab, int64_t slab_row0) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= r * K) return;
     const int64_t row = idx / K;
@@ -922,7 +922,8 @@ __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const f
     const int64_t o = (row_index ? (int64_t)row_index[row] : row) * K + k;
     const float f = F[row * Kp + k];
     float rr = R[row * Kp + k];
-    for (int sl = 1; sl < nslab; ++sl) rr += R[((int64_t)sl * r + row) * Kp + k];      // oriana_row_pass_split
+    const int ns = row >= slab_row0 ? nslab : 1;                                        // (oriana_row_split: full row blocks have slab 0 only)
+    for (int sl = 1; sl < ns; ++sl) rr += R[((int64_t)sl * r + row) * Kp + k];         // oriana_row_pass_split
     float v = f * rr;
     if (mul) v *= mul[o];
     // (+ 0: a dead factor row is -0.0; the outputs carry +0.  The accumulating form without a multiplier is spelled as
@@ -1085,12 +1086,33 @@ struct Stage {
 };
 
 // ---- row pass ------------------------------------------------------------------------------------
+// Row-block item of a two-lane row kernel under an oriana_row_split: full row blocks first (one group each), then the
+// parts of the split ones
+struct RowItem { int64_t rb; int cb0, cb1, slab; };
+__device__ __forceinline__ RowItem row_item(const oriana_counts &cm, const oriana_row_split &sp) {
+    RowItem it;
+    const int b = (int)blockIdx.x;
+    if (b < sp.nfull) { it.rb = b; it.cb0 = 0; it.cb1 = (int)cm.ncb; it.slab = 0; return it; }
+    const int idx = b - sp.nfull;
+    const int blk = idx / sp.parts, part = idx - blk * sp.parts;
+    it.rb = sp.nfull + blk; it.slab = part;
+    if (sp.edge[0] < 0) {                        // evenly cut ranges (any number of parts)
+        it.cb0 = (int)((int64_t)part * cm.ncb / sp.parts); it.cb1 = (int)(((int64_t)part + 1) * cm.ncb / sp.parts);
+        return it;
+    }
+    it.cb0 = sp.edge[0]; it.cb1 = sp.edge[1];
+    #pragma unroll
+    for (int e = 1; e < 8; ++e)
+        if (part == e) { it.cb0 = sp.edge[e]; it.cb1 = sp.edge[e + 1]; }
+    return it;
+}
+
 template <int TAIL, int VAR>
 __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const float *__restrict__ FU,
                                                        const float *__restrict__ FV, const float *__restrict__ w_nz,
                                                        float *__restrict__ R, float *__restrict__ s_cs,
                                                        float *__restrict__ sw_cs, float *__restrict__ s_rs,
-                                                       int32_t *__restrict__ tile_flag) {
+                                                       int32_t *__restrict__ tile_flag, oriana_row_split split) {
     constexpr bool SROW = (VAR & 1) != 0, HASW = (VAR & 2) != 0;
     constexpr int KP = 96 + 4 * TAIL, KP4 = KP / 4;
     constexpr int PD = 3;                       // record prefetch depth (iterations)
@@ -1099,7 +1121,8 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 1, g = (lane >> 1) & 15;
     const int sl = wave * 2 + (lane >> 5);      // slice of this half wave
-    const int64_t rb = blockIdx.x;
+    const RowItem item = row_item(cm, split);   // row block, gene tiles [cb0, cb1), slab of R
+    const int64_t rb = item.rb;
     const int64_t row = rb * TILE + sl * 16 + g;
     const int slot_lane = g * 4 + 2 * q;        // this lane's two records inside a 64-slot iteration
     const int toff = ((lane >> 1) & 3) * 4 + 2 * q;      // float offset inside the 4-fold tail of an image row
@@ -1126,8 +1149,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         rowfilled = !(fm == 1.0f);
     }
 
-    // gridDim.y > 1: gene tiles [cb0, cb1) of the row block, row sums stored in slab blockIdx.y of R (see k_row_pass)
-    const int64_t cb0 = (int64_t)blockIdx.y * cm.ncb / gridDim.y, cb1 = ((int64_t)blockIdx.y + 1) * cm.ncb / gridDim.y;
+    const int64_t cb0 = item.cb0, cb1 = item.cb1;
     for (int64_t cb = cb0; cb < cb1; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
         const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
@@ -1225,7 +1247,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n && !SROW) {
-        float *Rs = R + (int64_t)blockIdx.y * cm.n * KP;
+        float *Rs = R + (int64_t)item.slab * cm.n * KP;
         #pragma unroll
         for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(Rs)[row * KP4 + gchunk(lane, t)] = acc[t];
         if (TAIL) *reinterpret_cast<f2 *>(Rs + row * KP + 96 + 2 * q) = acct;
@@ -1513,7 +1535,8 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
                                                       const float *__restrict__ FV, const float *__restrict__ w_nz,
                                                       float *__restrict__ R, float *__restrict__ s_cs,
                                                       float *__restrict__ sw_cs, float *__restrict__ s_rs,
-                                                      int32_t *__restrict__ tile_flag, const float *__restrict__ FV2) {
+                                                      int32_t *__restrict__ tile_flag, const float *__restrict__ FV2,
+                                                      oriana_row_split split) {
     constexpr bool F2I = (VAR & 4) != 0;
     constexpr bool SPARSE = (VAR & 5) != 0, SROW = (VAR & 1) != 0 && !F2I, HASW = (VAR & 2) != 0;
     constexpr int KP = 4 * KP4;
@@ -1522,7 +1545,8 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 1, g = (lane >> 1) & 15;
     const int sl = wave * 2 + (lane >> 5);      // slice of this half wave
-    const int64_t rb = blockIdx.x;
+    const k100::RowItem item = k100::row_item(cm, split);   // row block, gene tiles [cb0, cb1), slab of R
+    const int64_t rb = item.rb;
     const int64_t row = rb * TILE + sl * 16 + g;
     const int slot_lane = g * 4 + 2 * q;        // this lane's two records inside a 64-slot iteration
 
@@ -1547,8 +1571,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
         rowfilled = !(fm == 1.0f);
     }
 
-    // gridDim.y > 1: gene tiles [cb0, cb1) of the row block, row sums stored in slab blockIdx.y of R (see k_row_pass)
-    const int64_t cb0 = (int64_t)blockIdx.y * cm.ncb / gridDim.y, cb1 = ((int64_t)blockIdx.y + 1) * cm.ncb / gridDim.y;
+    const int64_t cb0 = item.cb0, cb1 = item.cb1;
     for (int64_t cb = cb0; cb < cb1; ++cb) {
         const int64_t t = rb * cm.ncb + cb;
         const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
@@ -1662,7 +1685,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n && !SROW) {
-        float *Rs = R + (int64_t)blockIdx.y * cm.n * KP;
+        float *Rs = R + (int64_t)item.slab * cm.n * KP;
         #pragma unroll
         for (int t = 0; t < T4; ++t)
             if (lidx[t] < KP4) reinterpret_cast<f4 *>(Rs)[row * KP4 + lidx[t]] = acc[t];
@@ -2132,18 +2155,21 @@ static inline size_t lds_bytes(int G, int T4, int TAIL) {
 template <int G, int T4, int TAIL>
 static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
                            float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s,
-                           const float *FV2 = nullptr, int gene_splits = 1) {
+                           const float *FV2, const oriana_row_split &sp) {
     const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
+    // two-lane kernels: one group per full row block, then the parts of the split ones (row_item)
+    const int64_t items = (int64_t)sp.nfull + (cm->nrb - sp.nfull) * sp.parts;
+    if (items > 0x7fffffffLL) return ORIANA_EINVAL;
     if constexpr (k64_cfg(G, T4, TAIL)) {
         if (k64_kernels() && !(FV2 && s_rs)) {
             constexpr int KP4 = 4 * T4 + TAIL;
             const size_t lb6 = (size_t)k64::IMG4 * 16 * (FV2 ? 2 : 1);
-            const dim3 grid6((unsigned)cm->nrb, (unsigned)gene_splits);
+            const dim3 grid6((unsigned)items);
 #define ORIANA_RP6(V)                                                                                 \
             rc = set_lds(k64::k_row_pass_k64<KP4, V>, lb6);                                           \
             if (rc) return rc;                                                                        \
-            hipLaunchKernelGGL((k64::k_row_pass_k64<KP4, V>), grid6, dim3(512), lb6, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, FV2)
+            hipLaunchKernelGGL((k64::k_row_pass_k64<KP4, V>), grid6, dim3(512), lb6, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, FV2, sp)
             const int v6 = var | (FV2 ? 4 : 0);
             if (v6 == 0) { ORIANA_RP6(0); }
             else if (v6 == 1) { ORIANA_RP6(1); }
@@ -2156,11 +2182,15 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
             return 0;
         }
     }
+    // every other kernel: whole-grid split only, ranges cut evenly by the kernel (gridDim.y)
+    const bool whole_grid = sp.nfull == 0 || sp.parts == 1;
+    const int gene_splits = sp.parts;
     if (FV2) {
         // two images of 256 factor rows side by side: only where both fit (and the tile needs no column sub-tiles)
         constexpr int KP = 4 * G * T4 + G * TAIL;
         const size_t lb2 = 2 * lds_bytes(G, T4, TAIL);
         if (use_k100(G, T4) || pick_nsub(KP) != 1 || lb2 > (size_t)LDS_BUDGET) return ORIANA_EKRANGE;
+        if (!whole_grid) return ORIANA_EINVAL;
         const dim3 grid2((unsigned)(cm->nrb * WaveGeo<G>::SPLIT), (unsigned)gene_splits), block2(1024);
         if (w_nz) {
             rc = set_lds(k_row_pass<G, T4, TAIL, 6>, lb2);
@@ -2174,6 +2204,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
         ORIANA_LAUNCH_CHECK();
         return 0;
     }
+    if (!use_k100(G, T4) && !whole_grid) return ORIANA_EINVAL;
     if constexpr (G == 4 && 4 * T4 + TAIL <= 8) {
         if (use_narrow(G, T4, TAIL) && var == 0) {
             constexpr int KP = 4 * G * T4 + G * TAIL;
@@ -2189,7 +2220,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
 #define ORIANA_RP2(V)                                                                                 \
         rc = set_lds(k100::k_row_pass_k100<TL, V>, lb2);                                              \
         if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)cm->nrb, (unsigned)gene_splits), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag)
+        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)items), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, sp)
         if (var == 0) { ORIANA_RP2(0); }
         else if (var == 1) { ORIANA_RP2(1); }
         else if (var == 2) { ORIANA_RP2(2); }
@@ -2427,6 +2458,26 @@ extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, 
     return oriana_factor_prep_pair_clear(FU, FV, logU, logV, maskV, row_index_u, row_index_v, n, m, K, scratch, nullptr, stream);
 }
 
+static oriana_row_split no_split(const oriana_counts *cm) {
+    oriana_row_split sp = {};
+    sp.nfull = (int32_t)cm->nrb; sp.parts = 1; sp.edge[0] = 0; sp.edge[1] = (int32_t)cm->ncb;
+    return sp;
+}
+static oriana_row_split even_split(const oriana_counts *cm, int64_t gene_splits) {        // oriana_row_pass_split
+    oriana_row_split sp = {};
+    sp.nfull = 0; sp.parts = (int32_t)gene_splits; sp.edge[0] = -1;
+    return sp;
+}
+static bool split_ok(const oriana_counts *cm, const oriana_row_split &sp) {
+    if (sp.nfull < 0 || sp.nfull > cm->nrb || sp.parts < 1 || sp.parts > 65535) return false;
+    if (cm->ncb > 0 && sp.parts > cm->ncb) return false;
+    if (sp.edge[0] < 0) return true;
+    if (sp.parts > 8 || sp.edge[0] != 0 || sp.edge[sp.parts] != cm->ncb) return false;
+    for (int e = 0; e < sp.parts; ++e)
+        if (sp.edge[e + 1] < sp.edge[e]) return false;
+    return true;
+}
+
 extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz,
                                float *R, float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, int64_t K,
                                void *stream) {
@@ -2437,7 +2488,8 @@ extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const f
     if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
     if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s)
+    const oriana_row_split sp = no_split(cm);
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s, nullptr, sp)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -2447,39 +2499,78 @@ extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const f
 // matrix of 10,000 cells runs the pass on 40 of the 256 CUs; splitting each row block's gene tiles over several groups
 // fills the chip; each group of a row block stores its row sums in its own slab of R, which the consumer adds up
 // (atomics on R cost 1.2 us per split at 10,000 x 20: more than the tile a split saves).
-extern "C" int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t K) {
+extern "C" int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const double *tile_cost, oriana_row_split *out) {
+    if (!cm || !out || cm->nrb < 0 || cm->nrb > 0x7fffffffLL || cm->ncb > 0x7fffffffLL) return ORIANA_EINVAL;
+    *out = no_split(cm);
     KCfg cfg;
-    if (!cm || !pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 1;
-    const int64_t groups = cm->nrb * ((use_k100(cfg.G, cfg.T4) || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (256 / (16 * (64 / cfg.G))));
+    if (!pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 0;
+    const bool two_lane = use_k100(cfg.G, cfg.T4) || (k64_kernels() && k64_cfg(cfg.G, cfg.T4, cfg.TAIL));
+    const int64_t groups = cm->nrb * ((two_lane || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (256 / (16 * (64 / cfg.G))));
     static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
-    if (groups >= 256 && forced <= 0) {
-        // Between one and eight rounds of the chip the two-lane kernels (one 512-thread group per CU: the image and the
-        // registers leave room for one) lose up to a third of the time to the last, partly filled round -- 391 row blocks
-        // (configs[2]) run as two rounds.  A split into sp gene ranges makes the rounds sp times shorter: cost
-        // ceil(groups * sp / 256) / sp rounds, + 2 % per extra range for its restaging; taken from a predicted 8 % on.
-        // Measured (tools/perf_row_splits.py): 100,000 x 20,000, K = 50: 2.11 -> 1.81 ms (sp = 3); 150,000 x 25,000,
-        // K = 64: 4.11 -> 3.32 ms (sp = 5); 125,000 x 30,000, K = 100 (1.91 rounds): 4.59 -> 4.72 ms, hence the model.
-        const bool one_group_per_cu = use_k100(cfg.G, cfg.T4) || (k64_kernels() && k64_cfg(cfg.G, cfg.T4, cfg.TAIL));
-        static const bool rounds_off = [] { const char *e = getenv("ORIANA_ROW_SPLIT_ROUNDS"); return e && !strcmp(e, "off"); }();
-        if (!one_group_per_cu || groups >= 8 * 256 || rounds_off) return 1;
-        double best = (double)((groups + 255) / 256);
-        const double base = best;
-        int64_t best_sp = 1;
-        for (int64_t sp = 2; sp <= 8 && sp <= cm->ncb; ++sp) {
-            const double c = (double)((groups * sp + 255) / 256) / (double)sp * (1.0 + 0.02 * (double)(sp - 1));
-            if (c < 0.98 * best) { best = c; best_sp = sp; }          // (a finer split has to earn its slabs)
+    static const bool rounds_off = [] { const char *e = getenv("ORIANA_ROW_SPLIT_ROUNDS"); return e && !strcmp(e, "off"); }();
+    int64_t nfull = 0, parts = 1;
+    if (forced > 0) {
+        parts = forced;
+    } else if (groups < 256) {
+        // short matrices: two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20:
+        // 77 / 42 / 25 / 24 us for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
+        parts = 512 / groups;
+    } else if (two_lane && !rounds_off) {
+        // One 512-thread group per CU (the image and the registers leave room for one): the pass advances in rounds of 256
+        // row blocks and a partly filled last round costs a whole one (1M x 30k, K = 100: 3840 / 3907 / 4096 row blocks =
+        // 33.9 / 35.8 / 36.2 ms; 391 row blocks -- configs[2] -- run as two rounds).  The row blocks of the last round are
+        // split into p gene ranges each: ceil(tail * p / 256) / p rounds instead of one, + 1 % per extra range; a finer
+        // split has to earn 3 %.
+        const int64_t tail = cm->nrb % 256;
+        if (tail == 0) return 0;
+        double best = 1.0;
+        int64_t bp = 1;
+        for (int64_t p2 = 2; p2 <= 8 && p2 <= cm->ncb; ++p2) {
+            const double c = (double)((tail * p2 + 255) / 256) / (double)p2 + 0.01 * (double)(p2 - 1);
+            if (c < 0.97 * best) { best = c; bp = p2; }
         }
-        if (best > 0.92 * base) return 1;
-        const int64_t per = (cm->ncb + best_sp - 1) / best_sp;
-        return (cm->ncb + per - 1) / per;
+        if (bp == 1) return 0;
+        nfull = cm->nrb - tail; parts = bp;
+    } else {
+        return 0;
     }
-    // two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20: 77 / 42 / 25 / 24 us
-    // for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
-    int64_t sp = forced > 0 ? forced : 512 / groups;
-    if (sp > cm->ncb) sp = cm->ncb;
-    if (sp < 1) sp = 1;
-    const int64_t per = (cm->ncb + sp - 1) / sp;
-    return (cm->ncb + per - 1) / per;
+    if (parts > cm->ncb) parts = cm->ncb;
+    if (parts <= 1) return 0;
+    {   // whole tiles per range: fewer parts if the tiles do not go round
+        const int64_t per = (cm->ncb + parts - 1) / parts;
+        parts = (cm->ncb + per - 1) / per;
+    }
+    out->nfull = (int32_t)nfull; out->parts = (int32_t)parts;
+    if (!two_lane || parts > 8) { out->edge[0] = -1; return 0; }       // evenly cut (gridDim.y kernels / many short ranges)
+    // equal-cost cut points (genes are packed by decreasing density: the first tiles are the long ones)
+    double total = 0.0;
+    for (int64_t c = 0; c < cm->ncb; ++c) total += tile_cost ? (tile_cost[c] > 0.0 ? tile_cost[c] : 0.0) : 1.0;
+    if (!(total > 0.0)) { out->edge[0] = -1; return 0; }
+    out->edge[0] = 0;
+    double cum = 0.0;
+    int64_t c = 0;
+    for (int64_t e = 1; e < parts; ++e) {
+        const double want = total * (double)e / (double)parts;
+        while (c < cm->ncb) {
+            const double w = tile_cost ? (tile_cost[c] > 0.0 ? tile_cost[c] : 0.0) : 1.0;
+            if (cum + 0.5 * w > want) break;
+            cum += w; ++c;
+        }
+        // every range keeps at least one tile
+        const int64_t lo = out->edge[e - 1] + 1, hi = cm->ncb - (parts - e);
+        int64_t edge = c < lo ? lo : (c > hi ? hi : c);
+        while (c < edge) { cum += tile_cost ? (tile_cost[c] > 0.0 ? tile_cost[c] : 0.0) : 1.0; ++c; }
+        out->edge[e] = (int32_t)edge;
+    }
+    out->edge[parts] = (int32_t)cm->ncb;
+    return 0;
+}
+
+// (round 3's interface: the number of gene ranges of a whole-grid split; 1 when the plan splits the last round only)
+extern "C" int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t K) {
+    oriana_row_split sp;
+    if (oriana_row_pass_plan(cm, K, nullptr, &sp) != 0) return 1;
+    return sp.nfull == 0 ? sp.parts : 1;
 }
 
 extern "C" int oriana_row_pass_split(const oriana_counts *cm, const float *FU, const float *FV, float *R, float *s_cs,
@@ -2491,7 +2582,8 @@ extern "C" int oriana_row_pass_split(const oriana_counts *cm, const float *FU, c
     if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
     if (gene_splits < 1 || gene_splits > 65535 || (cm->ncb > 0 && gene_splits > cm->ncb)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, nullptr, R, s_cs, nullptr, nullptr, tile_flag, s, nullptr, (int)gene_splits)
+    const oriana_row_split sp = even_split(cm, gene_splits);
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, nullptr, R, s_cs, nullptr, nullptr, tile_flag, s, nullptr, sp)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -2508,7 +2600,8 @@ extern "C" int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, 
     if ((w_nz != nullptr) != (sw_cs != nullptr)) return ORIANA_EINVAL;
     if (cm->m == 0) return oriana_row_pass(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, K, stream);
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, s, FV2)
+    const oriana_row_split sp = no_split(cm);
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, s, FV2, sp)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -2518,17 +2611,18 @@ extern "C" int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, 
 // tiles of a row block split over gene_splits work-groups, each storing its row sums in its own slab of R.
 extern "C" int oriana_row_pass_general(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
                                        const float *w_nz, float *R, float *s_cs, float *sw_cs, float *s_rs,
-                                       int32_t *tile_flag, int64_t K, int64_t gene_splits, void *stream) {
+                                       int32_t *tile_flag, int64_t K, const oriana_row_split *split, void *stream) {
     if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
     KCfg cfg;
     if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
     if (cm->n == 0) return 0;
     if (!FU || !R || (cm->m > 0 && !FV) || (cm->m > 0 && (!s_cs || !tile_flag))) return ORIANA_EINVAL;
     if ((w_nz != nullptr) != (sw_cs != nullptr) || (FV2 && s_rs)) return ORIANA_EINVAL;
-    if (gene_splits < 1 || gene_splits > 65535 || (cm->ncb > 0 && gene_splits > cm->ncb)) return ORIANA_EINVAL;
+    const oriana_row_split sp = split ? *split : no_split(cm);
+    if (!split_ok(cm, sp)) return ORIANA_EINVAL;
     if (cm->m == 0) FV2 = nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s, FV2, (int)gene_splits)
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s, FV2, sp)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;
@@ -2657,23 +2751,28 @@ extern "C" int oriana_finalize(float *Z, const float *F, const float *R, const f
     if (!Z || !F || !R) return ORIANA_EINVAL;
     const int64_t tot = r * K;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, F, R,
-                       mul, row_index, r, (int)K, (int)Kp, accumulate, 1);
+                       mul, row_index, r, (int)K, (int)Kp, accumulate, 1, (int64_t)0);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_finalize_slabs_from(float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0,
+                                          const int32_t *row_index, int64_t r, int64_t K, void *stream) {
+    const int64_t Kp = oriana_kpad(K);
+    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535 || slab_row0 < 0) return ORIANA_EINVAL;
+    if (Kp == 0) return ORIANA_EKRANGE;
+    if (r == 0) return 0;
+    if (!Z || !F || !R) return ORIANA_EINVAL;
+    const int64_t tot = r * K;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, F, R,
+                       (const float *)nullptr, row_index, r, (int)K, (int)Kp, 1, (int)nslab, slab_row0);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int oriana_finalize_slabs(float *Z, const float *F, const float *R, int64_t nslab, const int32_t *row_index,
                                      int64_t r, int64_t K, void *stream) {
-    const int64_t Kp = oriana_kpad(K);
-    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535) return ORIANA_EINVAL;
-    if (Kp == 0) return ORIANA_EKRANGE;
-    if (r == 0) return 0;
-    if (!Z || !F || !R) return ORIANA_EINVAL;
-    const int64_t tot = r * K;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, F, R,
-                       (const float *)nullptr, row_index, r, (int)K, (int)Kp, 1, (int)nslab);
-    ORIANA_LAUNCH_CHECK();
-    return 0;
+    return oriana_finalize_slabs_from(Z, F, R, nslab, 0, row_index, r, K, stream);
 }
 
 extern "C" int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag, float *s_cs, float *sw_cs,

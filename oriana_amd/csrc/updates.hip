@@ -32,7 +32,7 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
                                                       const float *__restrict__ rmul, int64_t r, int K, int rpb,
                                                       float *__restrict__ Zfin, const float *__restrict__ F,
                                                       const float *__restrict__ Rs, const int32_t *__restrict__ row_index,
-                                                      int Kp, int nslab) {
+                                                      int Kp, int nslab, int64_t slab_row0) {
     const float *Z = FIN ? Zfin : Z_in;
     __shared__ double red[2][NT];
     const int KT = blockDim.x, RY = blockDim.y;
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
                 double s1, s2;
                 if (FIN) {
                     float rr = Rs[row * Kp + k];
-                    for (int sl = 1; sl < nslab; ++sl) rr += Rs[((int64_t)sl * r + row) * Kp + k];
+                    const int ns = row >= slab_row0 ? nslab : 1;
+                    for (int sl = 1; sl < ns; ++sl) rr += Rs[((int64_t)sl * r + row) * Kp + k];
                     const float zf = fmaf(F[row * Kp + k], rr, Zfin[idx]) + 0.0f;                  // k_finalize (accumulate)
                     Zfin[idx] = zf;
                     s1 = clamp_eps(prior1[k] + (double)zf);
@@ -256,20 +257,20 @@ extern "C" int oriana_gamma_update(double *a1, double *a2, double *E, float *Elo
     if (big)
         hipLaunchKernelGGL((k_gamma_update<false, 512>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
                            colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, rpb,
-                           (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, 0, 1);
+                           (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, 0, 1, (int64_t)0);
     else
         hipLaunchKernelGGL((k_gamma_update<false, 256>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
                            colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, rpb,
-                           (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, 0, 1);
+                           (float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, 0, 1, (int64_t)0);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int oriana_gamma_update_finalize(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+extern "C" int oriana_gamma_update_finalize_from(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
                                             double *colsum_Elog, const double *prior1, const double *prior2, float *Z,
-                                            const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                                            const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
                                             const double *rate_vec, int64_t r, int64_t K, void *stream) {
-    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535) return ORIANA_EINVAL;
+    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535 || slab_row0 < 0) return ORIANA_EINVAL;
     const int64_t Kp = oriana_kpad(K);
     if (K > 128 * GU_MAXCOLS_PER_THREAD || Kp == 0) return ORIANA_EKRANGE;
     if (r == 0) return 0;
@@ -282,13 +283,21 @@ extern "C" int oriana_gamma_update_finalize(double *a1, double *a2, double *E, f
     if (big)
         hipLaunchKernelGGL((k_gamma_update<true, 1024>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
                            colsum_E, colsum_Elog, prior1, prior2, (const float *)nullptr, (const float *)nullptr, rate_vec,
-                           (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab);
+                           (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0);
     else
         hipLaunchKernelGGL((k_gamma_update<true, 256>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
                            colsum_E, colsum_Elog, prior1, prior2, (const float *)nullptr, (const float *)nullptr, rate_vec,
-                           (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab);
+                           (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0);
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_gamma_update_finalize(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+                                            double *colsum_Elog, const double *prior1, const double *prior2, float *Z,
+                                            const float *F, const float *R, int64_t nslab, const int32_t *row_index,
+                                            const double *rate_vec, int64_t r, int64_t K, void *stream) {
+    return oriana_gamma_update_finalize_from(a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, Z, F, R, nslab, 0, row_index,
+                                             rate_vec, r, K, stream);
 }
 
 extern "C" int oriana_colsum_f64(double *out, const double *A, const float *mul, int64_t r, int64_t K, void *stream) {

@@ -216,6 +216,13 @@ class CountTiles:
 
     def finish(self):
         self._col_work = {}
+        # relative cost of the gene tiles on the row side (mean iterations of a 16-row slice + the staging of the tile's factor
+        # rows, in iterations): where the row pass cuts gene ranges (oriana_row_pass_plan)
+        self.gene_tile_cost = None
+        if self.tile_rslots is not None and self.nrb * self.ncb > 0:
+            per = self.tile_rslots[:self.nrb * self.ncb].view(self.nrb, self.ncb).to(torch.float64).mean(dim=0) / (16 * 64)
+            stage = float(os.environ.get('ORIANA_TILE_STAGE_COST', '2.0'))        # (tuning runs)
+            self.gene_tile_cost = np.ascontiguousarray((per + stage).cpu().numpy(), dtype=np.float64)
         self.tile_rslots = self.tile_cslots = None
         if self.gd and self.col_perm is None:
             raise _lib.OrianaHipError('a hybrid layout needs an explicit gene order')
@@ -497,10 +504,18 @@ class ZWorkspace:
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
         self._clear_cache = {}
-        # gene-tile split of the plain row pass (short matrices; 1 = one work-group per row block)
-        self.row_gene_splits = 1
+        # gene-range split of the row pass (struct oriana_row_split: short matrices split every row block, long ones the row
+        # blocks of the last, partly filled round of the chip); row_gene_splits = slabs of R, row_slab_row0 = first row with
+        # more than slab 0
+        self.row_split = _lib.OrianaRowSplit()
+        self.row_split.nfull, self.row_split.parts = max(ct.nrb, 0), 1
+        self.row_split.edge[0], self.row_split.edge[1] = 0, max(ct.ncb, 0)
         if ct.ms > 0 and ct.n > 0 and os.environ.get('ORIANA_ROW_SPLIT', 'auto') != 'off':
-            self.row_gene_splits = max(1, int(_lib.load().oriana_row_pass_gene_splits(ct.sparse_struct, int(K))))
+            cost = getattr(ct, 'gene_tile_cost', None)
+            call('oriana_row_pass_plan', ct.sparse_struct, int(K), cost.ctypes.data if cost is not None else None,
+                 ctypes.byref(self.row_split))
+        self.row_gene_splits = int(self.row_split.parts)
+        self.row_slab_row0 = int(self.row_split.nfull) * TILE
         gs = self.row_gene_splits
         self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32) if gs == 1 else torch.zeros(gs, ct.n, self.Kp, **f32)
         if ct.dense is not None:
@@ -519,6 +534,23 @@ class ZWorkspace:
                 self.dn_gene_splits = max(1, min(d.ngt, int(os.environ['ORIANA_DN_GENE_SPLITS'])))
             groups = (d.ngt + 7) // 8
             self.dn_cell_splits = max(1, min((ct.n + 31) // 32, (-(-1024 // groups) + 7) // 8 * 8))
+
+    def set_row_split(self, nfull, parts, edges=None):
+        """Replace the plan of oriana_row_pass_plan (tests, tuning runs): row blocks [0, nfull) whole, the others in `parts`
+        gene ranges cut at `edges` (parts + 1 gene-tile indices; None = evenly)."""
+        ct = self.ct
+        sp = self.row_split
+        sp.nfull, sp.parts = int(nfull), int(parts)
+        if edges is None:
+            sp.edge[0] = -1
+        else:
+            assert len(edges) == parts + 1 <= 9
+            for i, e in enumerate(edges):
+                sp.edge[i] = int(e)
+        self.row_gene_splits = int(parts)
+        self.row_slab_row0 = int(nfull) * TILE
+        f32 = dict(dtype=torch.float32, device=ct.device)
+        self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32) if parts == 1 else torch.zeros(parts, ct.n, self.Kp, **f32)
 
     def extra(self, name, rows):
         """Lazily allocated padded (rows, Kp) scratch factor / accumulator matrices."""
@@ -702,12 +734,8 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
         factor_prep_pair(ws, log_U_hat, log_V_hat, clear=(Z_hat_i, Z_hat_j, ws.C, ws.tile_flag, zero_R) + tuple(clear))
         if ct.ms > 0:
             with _span(ws, 'row_pass'):
-                if gs > 1:
-                    call('oriana_row_pass_split', ct.sparse_struct, ptr(ws.FU), FVs, ptr(ws.R), ptr(ws.s_cs),
-                         ptr(ws.tile_flag), K, gs, st)
-                else:
-                    call('oriana_row_pass', ct.sparse_struct, ptr(ws.FU), FVs, None, ptr(ws.R), ptr(ws.s_cs), None, None,
-                         ptr(ws.tile_flag), K, st)
+                call('oriana_row_pass_general', ct.sparse_struct, ptr(ws.FU), FVs, None, None, ptr(ws.R), ptr(ws.s_cs), None, None,
+                     ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), st)
         if dn is not None:
             with _span(ws, 'dense_images'):
                 call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
@@ -725,7 +753,7 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
                      ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_hat_i), ptr(Z_hat_j), None, None, None, None, K,
                      1 if zj_packed else 0, st)
         if finalize_rows:
-            call('oriana_finalize_slabs', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), gs, ptr(ct.row_perm), ct.n, K, st)
+            call('oriana_finalize_slabs_from', ptr(Z_hat_i), ptr(ws.FU), ptr(ws.R), gs, ws.row_slab_row0, ptr(ct.row_perm), ct.n, K, st)
     if phase in ('all', 'cols'):
         if ct.ms > 0:
             with _span(ws, 'col_pass'):
@@ -812,7 +840,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             if sparse and _FUSE_SPARSE_ROWS:
                 with _span(ws, 'row_pass'):
                     rc = _lib.load().oriana_row_pass_general(cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(F2) + goff, ptr(w_nz), ptr(ws.R),
-                                                             ptr(ws.s_cs), ptr(sw_cs), None, ptr(ws.tile_flag), K, gs, st)
+                                                             ptr(ws.s_cs), ptr(sw_cs), None, ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), st)
                 if rc not in (0, -2):
                     raise _lib.OrianaHipError('oriana_row_pass_general failed with code %d' % rc)
                 fused = rc == 0
@@ -821,7 +849,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
                     ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
                 with _span(ws, 'row_pass'):
                     call('oriana_row_pass_general', cst, ptr(ws.FU), ptr(ws.FV) + goff, None, ptr(w_nz), ptr(ws.R), ptr(ws.s_cs),
-                         ptr(sw_cs), ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, gs, st)
+                         ptr(sw_cs), ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), st)
             if fused or not sparse:
                 nslab = gs                       # (the second row product of the unfused sparse form writes one slab)
             with _span(ws, 'fixup'):
@@ -842,7 +870,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             with _span(ws, 'fixup'):
                 call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
                      ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, 0, st)
-        call('oriana_finalize_slabs', ptr(Z_i), ptr(ws.FU), ptr(ws.R), nslab, ptr(ct.row_perm), n, K, st)
+        call('oriana_finalize_slabs_from', ptr(Z_i), ptr(ws.FU), ptr(ws.R), nslab, ws.row_slab_row0, ptr(ct.row_perm), n, K, st)
         if Z_log is not None:
             # E[log U]-weighted row factor of the log sums: built NOW, from the pre-update E[log U] (the caller
             # may run the cell-side update between the two phases)

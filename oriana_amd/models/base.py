@@ -318,7 +318,7 @@ class FactorModel:
              ptr(p1.tensor), ptr(p2.tensor), ptr(Z) if update else None, ptr(zmul), ptr(rate_vec), ptr(rate_mat),
              ptr(rmul), r, self.k, stream_ptr())
 
-    def _gamma_side_finalize(self, side, Z, F, R, row_index, rate_vec, sums, nslab=1):
+    def _gamma_side_finalize(self, side, Z, F, R, row_index, rate_vec, sums, nslab=1, slab_row0=0):
         """pCMF: Z += F * R (the last step of the responsibility pass, packed rows scattered through `row_index`) and the
         Gamma update of that side in one launch (oriana_gamma_update_finalize).  `sums` (2, K) must be zero on entry."""
         if side == 'v':
@@ -327,9 +327,9 @@ class FactorModel:
             s1, s2, E, Elog, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self.alpha1, self.alpha2, self.n
         else:
             s1, s2, E, Elog, p1, p2, r = self.b1, self.b2, self._V_hat, self._log_V_hat, self.beta1, self.beta2, self.m
-        call('oriana_gamma_update_finalize', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
-             ptr(p1.tensor), ptr(p2.tensor), ptr(Z), ptr(F), ptr(R), int(nslab), ptr(row_index), ptr(rate_vec), r, self.k,
-             stream_ptr())
+        call('oriana_gamma_update_finalize_from', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
+             ptr(p1.tensor), ptr(p2.tensor), ptr(Z), ptr(F), ptr(R), int(nslab), int(slab_row0), ptr(row_index), ptr(rate_vec), r,
+             self.k, stream_ptr())
 
     def _mstep_side(self, side):
         if side == 'u':

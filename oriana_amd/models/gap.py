@@ -37,7 +37,8 @@ class GaP(FactorModel):
         engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows', finalize_rows=False,
                       clear=(self._sumU, self._accV) + ((self._Zj_o,) if packed else ()), zj_packed=packed)
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
-        self._gamma_side_finalize('u', self._Zi, ws.FU, ws.R, ct.row_perm, self._sumV[0], self._sumU, nslab=ws.row_gene_splits)
+        self._gamma_side_finalize('u', self._Zi, ws.FU, ws.R, ct.row_perm, self._sumV[0], self._sumU, nslab=ws.row_gene_splits,
+                                  slab_row0=ws.row_slab_row0)
         self._exchange_start()                  # sum_i U_hat | sum_i log U_hat (float64): reduced under the column pass
         engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='cols', finalize_cols=not fold_cols,
                       zj_packed=packed,

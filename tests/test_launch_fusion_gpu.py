@@ -129,16 +129,19 @@ def test_gene_split_rule(eng):
     import scipy.sparse as sp
     tall = eng.CountTiles.from_scipy(sp.random(70000, 600, density=0.01, format='csr', random_state=2, dtype=np.float32), 'cuda')
     assert tall.nrb >= 256 and eng.ZWorkspace(tall, 20).row_gene_splits == 1
-    # [r4] between one and eight rounds of the chip the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100) split by
-    # the round model: 391 row blocks are two rounds (three gene ranges: 5 / 3), 489 row blocks are two rounds whatever the split
+    # [r4] the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100) split the row blocks of a partly filled LAST round of
+    # the chip: 391 row blocks = 256 whole + 135 in five gene ranges (3 / 5 of a round); 489 = 256 + 233: two rounds anyway
     import os
     if os.environ.get('ORIANA_ROW_SPLIT_ROUNDS') != 'off' and not os.environ.get('ORIANA_PASS_IMPL'):
         c3 = eng.CountTiles.from_scipy(sp.random(100000, 1200, density=0.004, format='csr', random_state=3, dtype=np.float32), 'cuda')
         assert c3.nrb == 391 and c3.ncb == 5
-        assert eng.ZWorkspace(c3, 50).row_gene_splits == 3 and eng.ZWorkspace(c3, 100).row_gene_splits == 3
+        for K in (50, 100):                                                      # the 135 row blocks of the second round in 5 ranges
+            w = eng.ZWorkspace(c3, K)
+            assert (w.row_split.nfull, w.row_split.parts, w.row_slab_row0) == (256, 5, 65536) and w.R.shape[0] == 5
+            assert list(w.row_split.edge[:6]) == [0, 1, 2, 3, 4, 5]
         assert eng.ZWorkspace(c3, 20).row_gene_splits == 1                       # (narrow kernels: several groups per CU)
         c8 = eng.CountTiles.from_scipy(sp.random(125000, 1200, density=0.004, format='csr', random_state=4, dtype=np.float32), 'cuda')
-        assert c8.nrb == 489 and eng.ZWorkspace(c8, 100).row_gene_splits == 1
+        assert c8.nrb == 489 and eng.ZWorkspace(c8, 100).row_gene_splits == 1    # (233 row blocks in the last round: nothing to gain)
 
 
 @pytest.mark.parametrize('K', [20, 50, 64, 100])
@@ -168,14 +171,17 @@ def test_zq_with_gene_splits_matches_one_group_per_row_block(eng, K, nest):
     def run(splits):
         ws = eng.ZWorkspace(ct, K, need_sw=nest == 'weights')
         if splits is not None:
-            ws.row_gene_splits = splits
-            ws.R = torch.zeros(splits, n, ws.Kp, device='cuda') if splits > 1 else torch.zeros(n, ws.Kp, device='cuda')
+            ws.set_row_split(*splits)
         o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
         eng.zq(ws, o[0], o[1], o[2] if nest != 'weights' else None, lu, lv, **kw)
         torch.cuda.synchronize()
         return o[:2] + ([o[2]] if nest != 'weights' else [])
-    ref = run(1)
-    for splits in (2, ct.ncb):
+    assert ct.nrb == 3 and ct.ncb == 4
+    ref = run((3, 1, (0, 4)))
+    # every row block in 2 / 4 even ranges; the last two row blocks in 3 uneven ranges, the last one in 2 (the first in one piece)
+    for splits in ((0, 2), (0, 4), (1, 3, (0, 1, 2, 4)), (2, 2, (0, 3, 4))):
+        if splits[0] > 0 and K == 20:
+            continue                                               # (the narrow kernels split whole grids only)
         got = run(splits)
         for a, b in zip(got, ref):
             sc = b.abs().max(0, keepdim=True).values.clamp_min(1e-30)

@@ -1,6 +1,6 @@
 # -*- coding: utf-8 -*-
-"""Row pass of pCMF's loop nest against the gene-tile split of its row blocks (ORIANA_ROW_SPLITS=<forced split>, read once per
-process): python tools/perf_row_splits.py n m K [sweeps]."""
+"""Row pass of pCMF's loop nest against the gene-tile split of its row blocks (ORIANA_ROW_SPLITS=<forced whole-grid split>, ORIANA_ROW_SPLIT_ROUNDS=off:
+no split of the last round; read once per process): python tools/perf_row_splits.py n m K [sweeps]."""
 import os
 import sys
 
@@ -26,5 +26,6 @@ for _ in range(reps):
     engine.zq_gap(ws, Zi, Zj, lu, lv)
 torch.cuda.synchronize()
 s = ws.timer.summary()
-print('n=%d m=%d K=%d row blocks %d splits %d: row pass %.3f ms, col pass %.3f ms; check %.6e' % (
-    n, m, K, ct.nrb, ws.row_gene_splits, s['row_pass'][1], s['col_pass'][1], float(Zi.double().sum())))
+sp = ws.row_split
+print('n=%d m=%d K=%d row blocks %d whole %d parts %d edges %s: row pass %.3f ms, col pass %.3f ms; check %.6e' % (
+    n, m, K, ct.nrb, sp.nfull, sp.parts, list(sp.edge[:sp.parts + 1]), s['row_pass'][1], s['col_pass'][1], float(Zi.double().sum())))

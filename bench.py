@@ -175,8 +175,17 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
+    if rank != 0:
+        # ONE json line on the job's stdout: whatever a library prints on the other ranks' stdout (RCCL's version banner sits
+        # in the C stdio buffer until exit) goes to their stderr
+        sys.stdout.flush()
+        os.dup2(2, 1)
     out = measure(args, args.workload, args.steps, args.warmup, world, rank, dev, np, torch, dist,
                   cpu_rows=(None if args.no_cpu else args.cpu_rows))
+    if world > 1 or force_pg:
+        dist.barrier()
+        dist.destroy_process_group()
+    _flush_c_stdio()                 # (rank 0: the banner leaves the buffer BEFORE the line, not at exit after it)
     if rank == 0:
         # The other single-GPU configurations of BASELINE.json ride in the SAME json line (so that the driver's run, not
         # only profiles/, carries them): configs[2] (ZI-pCMF) and configs[4] (sparse pCMF), a short run each after the
@@ -190,10 +199,17 @@ def main():
                 except Exception as exc:            # never let an extra figure break the bench line
                     sub = {'workload': wl, 'error': repr(exc)[:300]}
                 out['secondary_workloads'].append(sub)
+        _flush_c_stdio()
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1 or force_pg:
-        dist.destroy_process_group()
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cpu_rows=None, brief=False):

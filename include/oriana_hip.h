@@ -278,6 +278,11 @@ int oriana_dense_images(void *img, const float *F, int64_t rows, int64_t K, int 
  * 1 where the tile of s holds sentinels). */
 int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
                           int32_t *flag, int64_t K, int64_t gene_splits, void *stream);
+/* [r4] ... with the 256-cell blocks from tail_nfull on split into tail_parts even gene-tile ranges, part p ADDING into slab p
+ * of R = (tail_parts, n, Kp) (struct oriana_row_split: the same rows as the sliced row pass of a hybrid layout splits; gene_splits
+ * must be 1 then).  tail_parts <= 1: oriana_dense_row_pass. */
+int oriana_dense_row_pass_tail(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
+                          int32_t *flag, int64_t K, int64_t gene_splits, int64_t tail_nfull, int64_t tail_parts, void *stream);
 /* Gene side: C[j,:] += sum_i s_ij FU[i,:] for the dense genes (atomics: zero C first), imgU = the cell-side images. */
 int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, const float *S, float *C, int64_t K,
                           int64_t cell_splits, void *stream);

@@ -67,6 +67,7 @@ _SIGS = {
     'oriana_dense_pack': (c_int, [_P, c_int, _I, _I, _I, _I, _P, _P]),
     'oriana_dense_images': (c_int, [_P, _P, _I, _I, c_int, _P]),
     'oriana_dense_row_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _P]),
+    'oriana_dense_row_pass_tail': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'oriana_dense_col_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _I, _I, _P]),
     'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_dense_metric': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -113,7 +113,7 @@ template <int KC, int TAIL>
 __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd, float *__restrict__ S,
                                                 const float *__restrict__ FU, const u4v *__restrict__ imgV,
                                                 float *__restrict__ R, int32_t *__restrict__ flag, int64_t n, int ngt,
-                                                int Kp, int gt_per_split, int atomic_out) {
+                                                int Kp, int gt_per_split, int atomic_out, int tail_nfull, int tail_parts) {
     using C = Cfg<KC, TAIL>;
     constexpr int NT = C::NT;
     extern __shared__ u4v ldsq[];
@@ -121,10 +121,22 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // (wave-uniform: addresses built from it stay scalar)
     float *T = reinterpret_cast<float *>(ldsq + 3 * C::PV) + w * 32 * TS;  // [wave][32 genes][TS]
-    const int64_t ct = (int64_t)blockIdx.x * NW + w;                       // this wave's cell tile
+    // tail_parts > 1 (struct oriana_row_split, as the two-lane sliced kernels): the 256-cell blocks [0, tail_nfull) are one
+    // work-group each; every later block is tail_parts groups over even gene-tile ranges, part p adding into slab p of R
+    // (plain read-modify-write: one group per (row, slab)) -- the last, partly filled round of the chip runs shorter groups
+    int blk = (int)blockIdx.x, gt0 = blockIdx.y * gt_per_split;
+    int gt1 = (gt0 + gt_per_split < ngt) ? gt0 + gt_per_split : ngt;
+    if (tail_parts > 1) {
+        gt0 = 0; gt1 = ngt;
+        if (blk >= tail_nfull) {
+            const int idx = blk - tail_nfull, q = idx / tail_parts, part = idx - q * tail_parts;
+            blk = tail_nfull + q;
+            gt0 = (int)((int64_t)part * ngt / tail_parts); gt1 = (int)(((int64_t)part + 1) * ngt / tail_parts);
+            R += (int64_t)part * n * Kp;
+        }
+    }
+    const int64_t ct = (int64_t)blk * NW + w;                              // this wave's cell tile
     const int64_t i = ct * 32 + c;
-    const int gt0 = blockIdx.y * gt_per_split;
-    const int gt1 = (gt0 + gt_per_split < ngt) ? gt0 + gt_per_split : ngt;
     if (gt0 >= gt1) return;
 
     // the wave's strip of FU as the B operand of the first product: per k chunk, factors 16 kc + 8 h + e of cell c
@@ -420,8 +432,8 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         buf = bufn;
     }
 #ifdef ORIANA_DN_STAMP
-    if (lane == 0 && (blockIdx.x % 61) == 7 && (w == 0 || w == 5))
-        printf("stamp blk %d w %d tiles %d: top->s15 %llu  s16-17 %llu  rest of A %llu  B %llu  vmcnt %llu  barrier %llu  (head %llu)\n", (int)blockIdx.x, w, gt1 - gt0,
+    if (lane == 0 && (blk % 61) == 7 && (w == 0 || w == 5))
+        printf("stamp blk %d w %d tiles %d: top->s15 %llu  s16-17 %llu  rest of A %llu  B %llu  vmcnt %llu  barrier %llu  (head %llu)\n", blk, w, gt1 - gt0,
                stamp_acc[1] / (gt1 - gt0), stamp_acc[2] / (gt1 - gt0), stamp_acc[3] / (gt1 - gt0), stamp_acc[4] / (gt1 - gt0), stamp_acc[5] / (gt1 - gt0), stamp_acc[6] / (gt1 - gt0), stamp_acc[0]);
 #endif
     // ---- the flags of the strip's tiles (every entry of flag[ct][gt0 .. gt1) is written)
@@ -880,19 +892,29 @@ extern "C" int oriana_dense_images(void *img, const float *F, int64_t rows, int6
     return oriana_dense_images2(img, F, F, rows, K, side, stream);
 }
 
-extern "C" int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
-                                     int32_t *flag, int64_t K, int64_t gene_splits, void *stream) {
+extern "C" int oriana_dense_row_pass_tail(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
+                                          int32_t *flag, int64_t K, int64_t gene_splits, int64_t tail_nfull, int64_t tail_parts,
+                                          void *stream) {
     int kc, tl, kp;
     if (!dense_ok(d) || K <= 0 || gene_splits < 1) return ORIANA_EINVAL;
     if (!dn_cfg(K, &kc, &tl, &kp)) return ORIANA_EKRANGE;
     if (d->gd == 0 || d->n == 0) return 0;
     if (!FU || !imgV || !R || !S || !flag) return ORIANA_EINVAL;
     const int ngt = (int)(d->gd / 32);
+    const int64_t nblk = d->nct / NW;
     int64_t splits = gene_splits < ngt ? gene_splits : ngt;
     if ((ngt + splits - 1) / splits > 2048) splits = (ngt + 2047) / 2048;      // (the kernel keeps one flag bit per tile in 64 x 32 bits)
     const int per = (int)((ngt + splits - 1) / splits);
     splits = (ngt + per - 1) / per;
-    const dim3 grid((unsigned)(d->nct / NW), (unsigned)splits);
+    dim3 grid((unsigned)nblk, (unsigned)splits);
+    if (tail_parts > 1) {            // the blocks from tail_nfull on in tail_parts even gene ranges (slabs of R), no other split
+        if (splits != 1 || tail_nfull < 0 || tail_nfull > nblk || tail_parts > ngt || tail_parts > 65535 || ngt > 2048) return ORIANA_EINVAL;
+        const int64_t items = tail_nfull + (nblk - tail_nfull) * tail_parts;
+        if (items > 0x7fffffffLL) return ORIANA_EINVAL;
+        grid = dim3((unsigned)items, 1u);
+    } else {
+        tail_nfull = nblk; tail_parts = 1;
+    }
     hipStream_t s = (hipStream_t)stream;
 #define ORIANA_DN_CALL(KC, TL)                                                                                              \
     do {                                                                                                                    \
@@ -900,12 +922,17 @@ extern "C" int oriana_dense_row_pass(const oriana_dense *d, const float *FU, con
         const int rc = set_lds(k_dn_row<KC, TL>, lb);                                                                       \
         if (rc) return rc;                                                                                                  \
         hipLaunchKernelGGL((k_dn_row<KC, TL>), grid, dim3(512), lb, s, d->x, S, FU, (const u4v *)imgV, R, flag, d->n, ngt,  \
-                           kp, per, splits > 1 ? 1 : 0);                                                                    \
+                           kp, per, splits > 1 ? 1 : 0, (int)tail_nfull, (int)tail_parts);                                  \
     } while (0)
     ORIANA_DN_FOR_CFG(kc, tl, ORIANA_DN_CALL);
 #undef ORIANA_DN_CALL
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
+                                     int32_t *flag, int64_t K, int64_t gene_splits, void *stream) {
+    return oriana_dense_row_pass_tail(d, FU, imgV, R, S, flag, K, gene_splits, 0, 1, stream);
 }
 
 extern "C" int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, const float *S, float *C, int64_t K,

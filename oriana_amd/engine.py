@@ -535,6 +535,15 @@ class ZWorkspace:
             groups = (d.ngt + 7) // 8
             self.dn_cell_splits = max(1, min((ct.n + 31) // 32, (-(-1024 // groups) + 7) // 8 * 8))
 
+    def dense_tail(self, nslab):
+        """(first split 256-cell block, parts) of the dense row kernel: the split of the sliced row pass's last round when the
+        row sums of this call have that many slabs (and the dense kernel no split of its own), else no split."""
+        sp = self.row_split
+        if sp.nfull > 0 and 1 < sp.parts == nslab and self.dn_gene_splits == 1 and sp.parts <= self.ct.dense.ngt \
+                and os.environ.get('ORIANA_DN_TAIL', 'on') != 'off':
+            return int(sp.nfull), int(sp.parts)
+        return 0, 1
+
     def set_row_split(self, nfull, parts, edges=None):
         """Replace the plan of oriana_row_pass_plan (tests, tuning runs): row blocks [0, nfull) whole, the others in `parts`
         gene ranges cut at `edges` (parts + 1 gene-tile indices; None = evenly)."""
@@ -740,8 +749,10 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
             with _span(ws, 'dense_images'):
                 call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
             with _span(ws, 'dense_row'):
-                call('oriana_dense_row_pass', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S),
-                     ptr(ws.dn_flag), K, ws.dn_gene_splits, st)
+                # (the blocks of the chip's last round split as the sliced row pass split them: same rows, same slabs of R)
+                tail = ws.dense_tail(gs)
+                call('oriana_dense_row_pass_tail', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S),
+                     ptr(ws.dn_flag), K, ws.dn_gene_splits, tail[0], tail[1], st)
         with _span(ws, 'fixup'):
             if ct.ms > 0:
                 # (packed Z_hat_j: the sliced part's packed gene 0 is row gd of the buffer)
@@ -865,8 +876,9 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             with _span(ws, 'dense_images'):
                 call('oriana_dense_images2', ptr(ws.dn_imgV), ptr(ws.FV), ptr(F2), gd, K, 0, st)
             with _span(ws, 'dense_row'):
-                call('oriana_dense_row_pass', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S), ptr(ws.dn_flag), K,
-                     ws.dn_gene_splits, st)
+                tail = ws.dense_tail(nslab)
+                call('oriana_dense_row_pass_tail', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S), ptr(ws.dn_flag), K,
+                     ws.dn_gene_splits, tail[0], tail[1], st)
             with _span(ws, 'fixup'):
                 call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
                      ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, 0, st)

@@ -188,6 +188,53 @@ def test_zq_with_gene_splits_matches_one_group_per_row_block(eng, K, nest):
             assert float(((a - b).abs() / (b.abs() + sc)).max()) < 3e-6, (splits, nest)
 
 
+@pytest.mark.parametrize('K', [50, 100])
+@pytest.mark.parametrize('nest', ['gap', 'zi_quirk', 'sparse'])
+def test_hybrid_layout_with_a_split_last_round(eng, K, nest):
+    """[r4] Hybrid layout: the dense row kernel splits the same 256-cell blocks as the sliced row pass and adds its parts into the
+    same slabs of R (oriana_dense_row_pass_tail) -- against the unsplit workspace of the same matrix."""
+    rng = np.random.default_rng(K)
+    n, m = 700, 900
+    dens = np.clip(rng.beta(1.0, 2.0, size=m), 0.02, 1.0)
+    dens[:160] = np.linspace(1.0, 0.5, 160)
+    X = (rng.poisson(3.0, size=(n, m)) + 1) * (rng.random((n, m)) < dens[None, :])
+    ct = eng.CountTiles.from_dense(X.astype(np.float32), 'cuda', dense_density=0.45)
+    assert ct.gd >= 128 and ct.ms > 0 and ct.nrb == 3
+    lu = torch.from_numpy(rng.normal(size=(n, K)).astype(np.float32)).cuda()
+    lv = torch.from_numpy((rng.normal(size=(m, K)) - 0.5).astype(np.float32)).cuda()
+    ps = rng.random((m, K))
+    kw = {}
+    if nest == 'sparse':
+        kw = dict(S_tilde=torch.from_numpy((ps > 0.3).astype(np.float32)).cuda(), S_hat=torch.from_numpy(ps.astype(np.float32)).cuda())
+    if nest == 'zi_quirk':
+        kw = dict(dq=torch.rand(n, K, device='cuda'))
+
+    def run(split):
+        ws = eng.ZWorkspace(ct, K)
+        ws.dn_gene_splits = 1
+        ws.set_row_split(*split)
+        o = [torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')]
+        if nest == 'gap':
+            eng.zq_gap(ws, o[0], o[1], lu, lv)
+            o = o[:2]
+        else:
+            eng.zq(ws, o[0], o[1], o[2], lu, lv, **kw)
+        torch.cuda.synchronize()
+        tail = ws.dense_tail(ws.row_gene_splits)
+        return o, tail
+    ref, t0 = run((ct.nrb, 1, (0, ct.ncb)))
+    assert t0 == (0, 1)
+    for split in ((1, 2, None), (2, 3, None), (1, 2, (0, 1, ct.ncb))):
+        if split[1] > ct.ncb:
+            continue
+        got, tail = run(split)
+        assert tail == (split[0], split[1])                   # (what a call with that many slabs hands the dense kernel; the
+        #                                                         unfused sparse form, K > 64, has one slab and no dense split)
+        for a, b in zip(got, ref):
+            sc = b.abs().max(0, keepdim=True).values.clamp_min(1e-30)
+            assert float(((a - b).abs() / (b.abs() + sc)).max()) < 3e-6, (split, nest)
+
+
 @pytest.mark.parametrize('r,K,perm,nslab', [(1000, 20, True, 1), (257, 100, False, 1), (3, 5, True, 3), (5000, 7, True, 4),
                                             (40000, 20, False, 1)])
 def test_gamma_update_with_folded_finalize(eng, r, K, perm, nslab):

@@ -286,6 +286,8 @@ def test_bench_self_launch_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
+    # ... and it is the LAST thing on stdout (RCCL's version banner leaves the C stdio buffer before it, not at exit)
+    assert r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-600:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
     assert d['config']['collectives_per_sweep'] == 3       # one exchange: float64 rate partials + the two segments of the packed per-gene sums
@@ -314,6 +316,7 @@ def test_rccl_single_rank_rehearsal():
         assert r.returncode == 0, (tag, r.stderr[-2000:])
         lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
         assert len(lines) == 1, r.stdout[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-600:]
         out[tag] = json.loads(lines[0])
     d = out['rccl']
     assert d['exchange_rehearsal']['backend'] == 'nccl' and d['exchange_rehearsal']['ranks'] == 1

@@ -130,21 +130,36 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
             if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; sq += mx * mx; cnt += 1.f; }
         }
         sum = wave_sum(sum); sq = wave_sum(sq); cnt = wave_sum(cnt);
-    } else
-    for (int64_t row = b0 * 4 + w; row < r; row += nb * 4) {
-        const float *l = logF + row * K;
-        const float *mk = mask ? mask + row * K : nullptr;
-        float mx = -INFINITY;
-        bool bad = false, any_on = false;
-        for (int k = lane; k < K; k += 64) {
-            const float v = l[k];
-            const bool on = mk ? (mk[k] != 0.0f) : true;
-            if (on) { any_on = true; if (v != v) bad = true; mx = fmaxf(mx, v); }
+    } else {
+        // one wave per row, FOUR rows of a wave in flight (a wave with one 400-byte read outstanding leaves the pass at
+        // 1 TB/s: 0.39 ms for the 400 MB of E[log U] at 1M cells); the rows are accumulated in the order of the plain loop
+        constexpr int RU = 4;
+        const int64_t step = nb * 4;
+        for (int64_t row0 = b0 * 4 + w; row0 < r; row0 += step * RU) {
+            float mx[RU];
+            bool bad[RU], any_on[RU];
+            #pragma unroll
+            for (int u = 0; u < RU; ++u) { mx[u] = -INFINITY; bad[u] = false; any_on[u] = false; }
+            for (int k = lane; k < K; k += 64) {
+                float v[RU], mv[RU];
+                #pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int64_t row = row0 + u * step;
+                    const bool in = row < r;
+                    v[u] = in ? logF[row * K + k] : 0.f;
+                    mv[u] = (in && mask) ? mask[row * K + k] : (in ? 1.0f : 0.0f);
+                }
+                #pragma unroll
+                for (int u = 0; u < RU; ++u)
+                    if (mv[u] != 0.0f) { any_on[u] = true; if (v[u] != v[u]) bad[u] = true; mx[u] = fmaxf(mx[u], v[u]); }
+            }
+            #pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const float m1 = wave_max(mx[u]);
+                const bool b1 = __any(bad[u]), a1 = __any(any_on[u]);
+                if (row0 + u * step < r && a1 && !b1 && fabsf(m1) <= STAT_MAX) { sum += m1; sq += m1 * m1; cnt += 1.f; }
+            }
         }
-        mx = wave_max(mx);
-        bad = __any(bad);
-        any_on = __any(any_on);
-        if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; sq += mx * mx; cnt += 1.f; }
     }
     if (lane == 0) { bs[w] = sum; bq[w] = sq; bc[w] = cnt; }
     __syncthreads();

@@ -187,20 +187,42 @@ class CountTiles:
             nit = nit.sum(axis=2) if os.environ.get('ORIANA_COL_PRICE') == 'sum' else nit.max(axis=2)
         cost = nit * 1.45 + 3.2
         total = float(cost.sum())
+        explicit_target = target_items
         if target_items is None:
             # 25-50 tiles per item (each item ends with one atomic flush of its accumulators), at least 9 per CU
             target_items = min(9216, max(2304, nt // (50 * width)))
-        target = max(total / target_items, 1e-9)
-        items = []
-        for cb in range(nblk):
-            cum = np.concatenate([[0.0], np.cumsum(cost[:, cb])])
-            nb = int(min(self.nrb, max(1, round(cum[-1] / target))))
-            # cut the column block at equal-cost points
-            edges = np.unique(np.searchsorted(cum, np.linspace(0.0, cum[-1], nb + 1)[1:-1], side='left'))
-            edges = np.concatenate([[0], edges, [self.nrb]]).astype(np.int64)
-            for a, e in zip(edges[:-1], edges[1:]):
-                if e > a:
-                    items.append((cum[e] - cum[a], cb, int(a), int(e)))
+        cums = [np.concatenate([[0.0], np.cumsum(cost[:, cb])]) for cb in range(nblk)]
+
+        def build(n_items):
+            target = max(total / n_items, 1e-9)
+            out = []
+            for cb in range(nblk):
+                cum = cums[cb]
+                nb = int(min(self.nrb, max(1, round(cum[-1] / target))))
+                # cut the column block at equal-cost points
+                edges = np.unique(np.searchsorted(cum, np.linspace(0.0, cum[-1], nb + 1)[1:-1], side='left'))
+                edges = np.concatenate([[0], edges, [self.nrb]]).astype(np.int64)
+                for a, e in zip(edges[:-1], edges[1:]):
+                    if e > a:
+                        out.append((cum[e] - cum[a], cb, int(a), int(e)))
+            return out
+        items = build(target_items)
+        # One 1024-thread group per CU and items of about equal cost: the pass advances in rounds of 256 items, and a partly
+        # filled last round costs a whole one.  Re-cut with slightly fewer items so that the count lands just below a
+        # multiple of 256 (ORIANA_COL_ROUNDS=off: the first cut).
+        if explicit_target is None and len(items) > 256 and os.environ.get('ORIANA_COL_ROUNDS', 'on') != 'off':
+            want = (len(items) // 256) * 256
+            t = target_items
+            trial = items
+            for _ in range(8):
+                if want - 24 <= len(trial) <= want:
+                    items = trial
+                    break
+                t = max(256, int(round(t * (want - 8) / max(len(trial), 1))))
+                trial = build(t)
+            else:
+                if want - 24 <= len(trial) <= want:
+                    items = trial
         items.sort(key=lambda x: (x[2] + x[3], x[1]))          # by row band: concurrent items share factor rows
         arr = np.asarray([[c, a, e] for _, c, a, e in items], dtype=np.int32)
         return torch.from_numpy(arr).to(self.device).contiguous()

@@ -27,5 +27,5 @@ for _ in range(reps):
 torch.cuda.synchronize()
 s = ws.timer.summary()
 sp = ws.row_split
-print('n=%d m=%d K=%d row blocks %d whole %d parts %d edges %s: row pass %.3f ms, col pass %.3f ms; check %.6e' % (
-    n, m, K, ct.nrb, sp.nfull, sp.parts, list(sp.edge[:sp.parts + 1]), s['row_pass'][1], s['col_pass'][1], float(Zi.double().sum())))
+print('n=%d m=%d K=%d col items %d row blocks %d whole %d parts %d edges %s: row pass %.3f ms, col pass %.3f ms; check %.6e' % (
+    n, m, K, int(ct.col_work_for(K).shape[0]), ct.nrb, sp.nfull, sp.parts, list(sp.edge[:sp.parts + 1]), s['row_pass'][1], s['col_pass'][1], float(Zi.double().sum())))

@@ -9,6 +9,11 @@ export TMPDIR=/tmp
 timeout 2700 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 1200 python3 bench.py --steps 20 --warmup 5 > $O/bench_c4.json 2> $O/bench_c4.err
 timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu --dense-density 0 > $O/bench_c4_sliced.json 2>/dev/null
+# the round-of-the-chip splits (row pass, dense row kernel, column work list) switched off, same box
+ORIANA_ROW_SPLIT_ROUNDS=off ORIANA_DN_TAIL=off ORIANA_COL_ROUNDS=off timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_c4_norounds.json 2>/dev/null
+for w in c3_zi c5_sparse; do
+  ORIANA_ROW_SPLIT_ROUNDS=off ORIANA_COL_ROUNDS=off timeout 900 python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu > $O/bench_${w}_norounds.json 2>/dev/null
+done
 for w in c2 c3_zi c5_sparse c4_eighth; do
   timeout 900 python3 bench.py --workload $w --steps 20 --warmup 5 > $O/bench_$w.json 2> $O/bench_$w.err
 done

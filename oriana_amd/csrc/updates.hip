@@ -74,8 +74,13 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
                     s1 = a1[idx];
                     s2 = a2[idx];
                 }
+#ifdef ORIANA_GU_ABL_NOSPECIAL                                      /* analysis build: the memory side of the kernel alone */
+                const double e = s1 * s2;
+                const float el = (float)s1 - (float)s2;
+#else
                 const double e = s1 / s2;                                // gamma.py:37-46
                 const float el = gamma_meanlog_f32(s1, s2);              // gamma.py:52-61
+#endif
                 E[idx] = e;
                 Elog[idx] = el;
                 sE[c] += e;

@@ -23,6 +23,17 @@ def _split_by_default():
     return os.environ.get('ORIANA_ROW_SPLIT', 'auto') != 'off' and not os.environ.get('ORIANA_ROW_SPLITS')
 
 
+def _two_lane_rows(K):
+    """Does the row pass of this K run on the two-lane kernels (the only ones that split single row blocks)?"""
+    import os
+    impl = os.environ.get('ORIANA_PASS_IMPL', '')
+    if 85 <= K <= 100:
+        return impl != 'r1'
+    if 33 <= K <= 64:
+        return impl not in ('r1', 'r2', 'r3')
+    return False
+
+
 def _counts(rng, n, m, density):
     X = rng.poisson(3.0, size=(n, m)).astype(np.int64) + 1
     X *= (rng.random((n, m)) < density)
@@ -180,8 +191,8 @@ def test_zq_with_gene_splits_matches_one_group_per_row_block(eng, K, nest):
     ref = run((3, 1, (0, 4)))
     # every row block in 2 / 4 even ranges; the last two row blocks in 3 uneven ranges, the last one in 2 (the first in one piece)
     for splits in ((0, 2), (0, 4), (1, 3, (0, 1, 2, 4)), (2, 2, (0, 3, 4))):
-        if splits[0] > 0 and K == 20:
-            continue                                               # (the narrow kernels split whole grids only)
+        if splits[0] > 0 and not _two_lane_rows(K):
+            continue                                               # (the other kernels split whole grids only)
         got = run(splits)
         for a, b in zip(got, ref):
             sc = b.abs().max(0, keepdim=True).values.clamp_min(1e-30)
@@ -224,12 +235,13 @@ def test_hybrid_layout_with_a_split_last_round(eng, K, nest):
         return o, tail
     ref, t0 = run((ct.nrb, 1, (0, ct.ncb)))
     assert t0 == (0, 1)
+    import os
     for split in ((1, 2, None), (2, 3, None), (1, 2, (0, 1, ct.ncb))):
-        if split[1] > ct.ncb:
+        if split[1] > ct.ncb or not _two_lane_rows(K):
             continue
         got, tail = run(split)
-        assert tail == (split[0], split[1])                   # (what a call with that many slabs hands the dense kernel; the
-        #                                                         unfused sparse form, K > 64, has one slab and no dense split)
+        # (what a call with that many slabs hands the dense kernel; the unfused sparse form, K > 64, has one slab and no dense split)
+        assert tail == ((split[0], split[1]) if os.environ.get('ORIANA_DN_TAIL', 'on') != 'off' else (0, 1))
         for a, b in zip(got, ref):
             sc = b.abs().max(0, keepdim=True).values.clamp_min(1e-30)
             assert float(((a - b).abs() / (b.abs() + sc)).max()) < 3e-6, (split, nest)

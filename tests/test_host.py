@@ -186,3 +186,49 @@ def test_bench_self_launch_reports_every_rank():
     tail = [l for l in r.stderr.splitlines() if l.startswith('[bench] rank ')]
     assert len(tail) == 2 and 'rank 0 rc=' in tail[0] and 'rank 1 rc=' in tail[1], r.stderr[-1500:]
     assert any('first to fail' in l for l in tail)
+
+
+def _plan(nrb, ncb, K, cost=None):
+    import ctypes
+    from oriana_amd import _lib
+    cm = _lib.OrianaCounts()
+    cm.n, cm.m, cm.nrb, cm.ncb = nrb * 256, ncb * 256, nrb, ncb
+    sp = _lib.OrianaRowSplit()
+    c = None
+    if cost is not None:
+        c = np.ascontiguousarray(cost, dtype=np.float64)
+    rc = _lib.load().oriana_row_pass_plan(ctypes.byref(cm), K, c.ctypes.data if c is not None else None, ctypes.byref(sp))
+    assert rc == 0
+    return sp.nfull, sp.parts, list(sp.edge[:sp.parts + 1])
+
+
+def test_row_pass_plan_rounds_of_the_chip(monkeypatch):
+    """oriana_row_pass_plan is host arithmetic (no GPU): the two-lane kernels (one work-group per CU) keep the row blocks of
+    the full rounds of 256 whole and cut those of the last round into gene ranges of equal cost; short matrices split every
+    row block; the other kernels and full last rounds do not split."""
+    for v in ('ORIANA_PASS_IMPL', 'ORIANA_ROW_SPLITS', 'ORIANA_ROW_SPLIT_ROUNDS'):
+        if os.environ.get(v):
+            pytest.skip('%s overrides the rule' % v)
+    # the headline: 3907 row blocks = 15 rounds + 67 row blocks, in three ranges (201 work-groups: one third of a round)
+    nfull, parts, edges = _plan(3907, 118, 100)
+    assert (nfull, parts, edges) == (3840, 3, [0, 39, 79, 118])
+    # equal COST: decreasing tile costs move the cut points towards the front
+    cost = np.linspace(10.0, 1.0, 118)
+    nfull, parts, edges = _plan(3907, 118, 100, cost)
+    assert (nfull, parts) == (3840, 3) and edges[0] == 0 and edges[3] == 118 and edges[1] < 39 and edges[2] < 79
+    c = np.add.reduceat(cost, edges[:-1])
+    assert c.max() / c.min() < 1.15
+    # configs[2]: 391 row blocks = 256 whole + 135 in five ranges; configs[4]: 1954 = 1792 + 162 in three
+    assert _plan(391, 79, 50)[:2] == (256, 5)
+    assert _plan(1954, 98, 64)[:2] == (1792, 3)
+    # a last round that is nearly full, or exactly full: nothing to gain
+    assert _plan(489, 118, 100)[:2] == (489, 1)
+    assert _plan(512, 118, 100)[:2] == (512, 1)
+    # kernels with several work-groups per CU (K = 20: one lane per row) keep whole row blocks from 256 on
+    assert _plan(391, 79, 20)[:2] == (391, 1)
+    # short matrices: every row block split (round 3's rule), evenly cut when there are more than 8 ranges
+    nfull, parts, edges = _plan(2, 118, 100)
+    assert nfull == 0 and parts == 118 and edges[0] == -1
+    assert _plan(40, 8, 20)[:2] == (0, 8)
+    # one gene tile: nothing to split
+    assert _plan(40, 1, 100)[:2] == (40, 1)

@@ -67,3 +67,57 @@ json.dump({'command': 'tools/evidence_r04_pmc.sh: two rocprofv3 --pmc passes per
 for w, der in sq_all.items():
     for k, e in der.items():
         print(w, k[:40], {a: round(b, 3) for a, b in e.items() if 'fraction' in a or 'wave_cycles' in a})
+
+# ---- C4, hybrid layout, final build (tools/evidence_r04_pmc_c4.sh)
+try:
+    fe = json.load(open(F + 'r04_c4_fetch.json'))['per_dispatch_mean']
+    wr = json.load(open(F + 'r04_c4_write.json'))['per_dispatch_mean']
+    s1 = json.load(open(F + 'r04_c4_sq1.json'))['per_dispatch_mean']
+    s2 = json.load(open(F + 'r04_c4_sq2.json'))['per_dispatch_mean']
+except FileNotFoundError:
+    fe = None
+if fe is not None:
+    def g(d, key):
+        for k, v in d.items():
+            if key in k:
+                return v[[c for c in v if c != '_dispatches'][0]]
+        return 0.0
+    tr = {'row_pass': (2 * g(fe, 'k_row_pass') + g(wr, 'k_row_pass')) * KiB, 'col_pass': (g(fe, 'k_col_pass') + g(wr, 'k_col_pass')) * KiB,
+          'dense_row': (2 * g(fe, 'k_dn_row') + g(wr, 'k_dn_row')) * KiB, 'dense_col': (2 * g(fe, 'k_dn_col') + g(wr, 'k_dn_col')) * KiB,
+          'dense_images': (g(fe, 'k_dn_images<6, 1, true>') + g(fe, 'k_dn_images<6, 1, false>') + g(wr, 'k_dn_images<6, 1, true>')
+                           + g(wr, 'k_dn_images<6, 1, false>')) * KiB,
+          'fixup': (g(fe, 'k_fixup') + g(fe, 'k_dn_fixup') + g(wr, 'k_fixup')) * KiB}
+    tr['total'] = sum(tr.values())
+    names = ('k_row_pass', 'k_col_pass', 'k_dn_row', 'k_dn_col', 'k_dn_images<6, 1, true>', 'k_dn_images<6, 1, false>', 'k_fixup', 'k_dn_fixup')
+    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu   (and a second, '
+                          'separate pass with --pmc WRITE_SIZE); tools/evidence_r04_pmc_c4.sh', 'workload': 'c4',
+               'layout': 'hybrid, threshold 0.2 (4064 dense genes); the row blocks of the last round of both row kernels split into three gene ranges',
+               'n_gpus': 1, 'unit': 'KB per launch, averaged over the launches of the run, as rocprofv3 reports them',
+               'counters': {k: {'FETCH_SIZE': g(fe, k), 'WRITE_SIZE': g(wr, k)} for k in names},
+               'corrections': 'MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read.  Doubled: the sliced '
+                              'row pass (8-byte records as 16-byte per-lane loads), the dense row kernel (counts as 16-byte per-lane loads, operand images by '
+                              '16-byte LDS-DMA) and the dense gene-side kernel (s and the operand images by 16-byte LDS-DMA).  The sliced column pass reads 4-byte '
+                              'and 1-byte per-lane streams plus factor tiles served by L2 / Infinity Cache: taken as counted.  WRITE_SIZE as counted; KB taken as KiB.',
+               'traffic_bytes_per_pass': tr, 'algorithmic_bytes': 120824000000.0}, open(P + 'r04_pmc_hbm_c4_hybrid.json', 'w'), indent=1)
+    sq, der = {}, {}
+    for d in (s1, s2):
+        for k, dd in d.items():
+            if any(t in k for t in ('k_row_pass', 'k_col_pass', 'k_dn_row', 'k_dn_col')):
+                sq.setdefault(k, {}).update({c: v for c, v in dd.items() if c != '_dispatches'})
+    for k, n in sq.items():
+        clk = n['GRBM_GUI_ACTIVE'] / 8.0
+        e = {'kernel_cycles': clk, 'valu_busy_fraction': n['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / clk,
+             'wave_cycles_waiting': n['SQ_WAIT_ANY'] / n['SQ_WAVE_CYCLES'], 'wave_cycles_issue_stalled': n['SQ_WAIT_INST_ANY'] / n['SQ_WAVE_CYCLES'],
+             'wave_cycles_issuing': n['SQ_ACTIVE_INST_ANY'] / n['SQ_WAVE_CYCLES'],
+             'lds_bank_conflict_fraction': n['SQ_LDS_BANK_CONFLICT'] / max(n['SQ_LDS_IDX_ACTIVE'], 1.0)}
+        if n.get('SQ_INSTS_MFMA'):
+            e['matrix_pipe_busy_fraction'] = n['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / clk
+            e['valu_instructions_per_matrix_instruction'] = n['SQ_INSTS_VALU'] / n['SQ_INSTS_MFMA']
+        der[k] = e
+    json.dump({'command': 'tools/evidence_r04_pmc_c4.sh: two rocprofv3 --pmc passes (8 SQ counters + GRBM_GUI_ACTIVE, counters only with --kernel-trace) over '
+                          'python3 bench.py --steps 2 --warmup 1 --no-cpu (c4, hybrid layout, final build)',
+               'unit': 'per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles',
+               'counters': sq, 'derived': der}, open(P + 'r04_sq_pass_c4_hybrid.json', 'w'), indent=1)
+    print('c4 hybrid traffic per pass %.1f GB' % (tr['total'] / 1e9), {k: round(v / 1e9, 2) for k, v in tr.items()})
+    for k, e in der.items():
+        print(k[:40], {a: round(b, 3) for a, b in e.items() if b is not None and ('fraction' in a or 'wave_cycles' in a)})

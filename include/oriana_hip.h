@@ -171,10 +171,8 @@ int oriana_row_pass(const oriana_counts *cm,
  * `gene_splits` work-groups: a row block is one work-group, so a matrix of 10,000 cells (configs[1]) ran the pass on 40
  * of the 256 CUs.  R is then (gene_splits, n, Kp): every group stores the row sums of its gene range in its own slab
  * (no atomics, nothing to clear); oriana_finalize_slabs / oriana_gamma_update_finalize add the slabs up.
- * oriana_row_pass_gene_splits: the split that fills the chip -- below 256 row-side work-groups, and [r4] between one and
- * eight rounds of the chip for the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100), where the last, partly
- * filled round costs up to a third of the pass (391 row blocks = configs[2]: 2.11 -> 1.81 ms with three gene ranges);
- * ORIANA_ROW_SPLIT_ROUNDS=off keeps round 3's rule. */
+ * oriana_row_pass_gene_splits: the split that fills the chip for a SHORT matrix (below 256 row-side work-groups; 1 from
+ * there on).  [r4] Long matrices: see oriana_row_pass_plan below, which splits the row blocks of the last round only. */
 int64_t oriana_row_pass_gene_splits(const oriana_counts *cm, int64_t K);
 int oriana_row_pass_split(const oriana_counts *cm, const float *FU, const float *FV, float *R, float *s_cs,
                           int32_t *tile_flag, int64_t K, int64_t gene_splits, void *stream);

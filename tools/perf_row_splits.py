@@ -14,7 +14,8 @@ n, m, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = torch.device('cuda')
 gen = SyntheticCounts(n, m, K, seed=77, device=dev, zero_inflation_level=0.1)
-ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, dev)
+ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, dev, sort_rows=os.environ.get('SORT_ROWS') == '1',
+                                   dense_density=float(os.environ['DENSE']) if os.environ.get('DENSE') else None)
 ws = engine.ZWorkspace(ct, K)
 lu = torch.randn(n, K, device=dev) * 0.3
 lv = torch.randn(m, K, device=dev) * 0.3
@@ -27,5 +28,6 @@ for _ in range(reps):
 torch.cuda.synchronize()
 s = ws.timer.summary()
 sp = ws.row_split
+print('slot efficiency', ct.slot_efficiency(), 'sort_rows', ct.sort_rows, 'gd', ct.gd)
 print('n=%d m=%d K=%d col items %d row blocks %d whole %d parts %d edges %s: row pass %.3f ms, col pass %.3f ms; check %.6e' % (
     n, m, K, int(ct.col_work_for(K).shape[0]), ct.nrb, sp.nfull, sp.parts, list(sp.edge[:sp.parts + 1]), s['row_pass'][1], s['col_pass'][1], float(Zi.double().sum())))

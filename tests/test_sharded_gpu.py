@@ -296,6 +296,29 @@ def test_bench_self_launch_two_ranks():
     assert 'K=100' in d['metric'] and '125k' in d['metric']
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own multi-GPU command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with two ranks on the one GPU of a test box (ORIANA_BENCH_ONE_GPU=1:
+    both use cuda:0, gloo stands in for RCCL): rank 0 prints the one JSON line, and it is the last line of the job's stdout."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORIANA_BENCH_ONE_GPU='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--workload', 'c2']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-600:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0 and d['scaling'] == 'strong'
+    assert len(d['per_rank_ms']['ranks']) == 2
+
+
 def test_rccl_single_rank_rehearsal():
     """The RCCL path itself, on the one GPU a test box has: `bench.py --gpus 1` with ORIANA_BENCH_FORCE_PG=1 initialises the
     nccl backend (= RCCL) with device_id= exactly as a multi-GPU launch does (bench.py main), and ORIANA_FORCE_SHARDED=1 makes

@@ -210,7 +210,17 @@ int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const double *tile_
  * Kernels other than the two-lane ones take nfull = 0 only (ORIANA_EINVAL otherwise) and cut their ranges evenly. */
 int oriana_row_pass_general(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
                             const float *w_nz, float *R, float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag,
-                            int64_t K, const oriana_row_split *split, void *stream);
+                            int64_t K, const oriana_row_split *split,
+                            const float *den_min,   /* device: the den threshold (scratch of oriana_factor_prep_pair +
+                                                       oriana_prep_den_threshold_offset()); NULL = the constant 1e-10 */
+                            void *stream);
+/* [r4] The den threshold of the shifted form: s = x / den' is trusted when den' >= threshold, below it the entry takes the
+ * exact slow path (oriana_fixup).  The guarantee behind it is that the reference's own float32 den = exp(mu_i + mv_j) den'
+ * is a normal number with room to spare (>= 3e-30); with the smallest sum mu_i + mv_j of the factor matrices at hand
+ * (row statistics of oriana_factor_prep_pair) the threshold is 3e-30 exp(-sum_lo) in [1e-25, 1e-10] instead of the
+ * worst-case constant 1e-10 -- ZI-pCMF drifts along U c, V / c and after 25 sweeps at configs[2] a third of the tiles
+ * held entries between the two.  ORIANA_DEN_THRESHOLD=fixed keeps the constant. */
+int64_t oriana_prep_den_threshold_offset(void);
 
 /* R[i,:] = sum_j w_ij s_ij FV[j,:] with s given in row-side slots (sparse models: S_hat-weighted sums). */
 int oriana_row_spmm(const oriana_counts *cm, const float *s_rs, const float *w_nz,
@@ -280,7 +290,8 @@ int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *im
  * of R = (tail_parts, n, Kp) (struct oriana_row_split: the same rows as the sliced row pass of a hybrid layout splits; gene_splits
  * must be 1 then).  tail_parts <= 1: oriana_dense_row_pass. */
 int oriana_dense_row_pass_tail(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
-                          int32_t *flag, int64_t K, int64_t gene_splits, int64_t tail_nfull, int64_t tail_parts, void *stream);
+                          int32_t *flag, int64_t K, int64_t gene_splits, int64_t tail_nfull, int64_t tail_parts,
+                               const float *den_min /* as oriana_row_pass_general */, void *stream);
 /* Gene side: C[j,:] += sum_i s_ij FU[i,:] for the dense genes (atomics: zero C first), imgU = the cell-side images. */
 int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, const float *S, float *C, int64_t K,
                           int64_t cell_splits, void *stream);

@@ -56,7 +56,8 @@ _SIGS = {
     'oriana_row_pass_split': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_row_spmm': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _I, _P]),
     'oriana_row_pass_masked': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    'oriana_row_pass_general': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, ctypes.POINTER(OrianaRowSplit), _P]),
+    'oriana_row_pass_general': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, ctypes.POINTER(OrianaRowSplit), _P, _P]),
+    'oriana_prep_den_threshold_offset': (_I, []),
     'oriana_row_pass_plan': (c_int, [ctypes.POINTER(OrianaCounts), _I, _P, ctypes.POINTER(OrianaRowSplit)]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
@@ -67,7 +68,7 @@ _SIGS = {
     'oriana_dense_pack': (c_int, [_P, c_int, _I, _I, _I, _I, _P, _P]),
     'oriana_dense_images': (c_int, [_P, _P, _I, _I, c_int, _P]),
     'oriana_dense_row_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _P]),
-    'oriana_dense_row_pass_tail': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'oriana_dense_row_pass_tail': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'oriana_dense_col_pass': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _I, _I, _P]),
     'oriana_dense_fixup': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_dense_metric': (c_int, [ctypes.POINTER(OrianaDense), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

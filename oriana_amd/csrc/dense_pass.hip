@@ -113,7 +113,9 @@ template <int KC, int TAIL>
 __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd, float *__restrict__ S,
                                                 const float *__restrict__ FU, const u4v *__restrict__ imgV,
                                                 float *__restrict__ R, int32_t *__restrict__ flag, int64_t n, int ngt,
-                                                int Kp, int gt_per_split, int atomic_out, int tail_nfull, int tail_parts) {
+                                                int Kp, int gt_per_split, int atomic_out, int tail_nfull, int tail_parts,
+                                                const float *__restrict__ den_min_p) {
+    const float den_min = den_min_p ? *den_min_p : DEN_MIN;              // (passes.hip, k_row_stats: the den threshold)
     using C = Cfg<KC, TAIL>;
     constexpr int NT = C::NT;
     extern __shared__ u4v ldsq[];
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     const uint32_t wd = xn[v >> 3][(v & 7) >> 1];
                     const uint32_t xi = (v & 1) ? (wd >> 16) : (wd & 0xFFFFu);
                     const float den = l0[v];
-                    const bool ok = den >= DEN_MIN;                        // false for 0, tiny and NaN
+                    const bool ok = den >= den_min;                        // false for 0, tiny and NaN
 #ifdef ORIANA_DN_ABL_VAND
                     okbits &= ok ? 0xFFFFFFFFu : 0u;               /* analysis switch: the running test on the vector ALU */
 #elif !defined(ORIANA_DN_ABL_NOAND)
@@ -894,7 +896,7 @@ extern "C" int oriana_dense_images(void *img, const float *F, int64_t rows, int6
 
 extern "C" int oriana_dense_row_pass_tail(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
                                           int32_t *flag, int64_t K, int64_t gene_splits, int64_t tail_nfull, int64_t tail_parts,
-                                          void *stream) {
+                                          const float *den_min, void *stream) {
     int kc, tl, kp;
     if (!dense_ok(d) || K <= 0 || gene_splits < 1) return ORIANA_EINVAL;
     if (!dn_cfg(K, &kc, &tl, &kp)) return ORIANA_EKRANGE;
@@ -922,7 +924,7 @@ extern "C" int oriana_dense_row_pass_tail(const oriana_dense *d, const float *FU
         const int rc = set_lds(k_dn_row<KC, TL>, lb);                                                                       \
         if (rc) return rc;                                                                                                  \
         hipLaunchKernelGGL((k_dn_row<KC, TL>), grid, dim3(512), lb, s, d->x, S, FU, (const u4v *)imgV, R, flag, d->n, ngt,  \
-                           kp, per, splits > 1 ? 1 : 0, (int)tail_nfull, (int)tail_parts);                                  \
+                           kp, per, splits > 1 ? 1 : 0, (int)tail_nfull, (int)tail_parts, den_min);                         \
     } while (0)
     ORIANA_DN_FOR_CFG(kc, tl, ORIANA_DN_CALL);
 #undef ORIANA_DN_CALL
@@ -932,7 +934,7 @@ extern "C" int oriana_dense_row_pass_tail(const oriana_dense *d, const float *FU
 
 extern "C" int oriana_dense_row_pass(const oriana_dense *d, const float *FU, const void *imgV, float *R, float *S,
                                      int32_t *flag, int64_t K, int64_t gene_splits, void *stream) {
-    return oriana_dense_row_pass_tail(d, FU, imgV, R, S, flag, K, gene_splits, 0, 1, stream);
+    return oriana_dense_row_pass_tail(d, FU, imgV, R, S, flag, K, gene_splits, 0, 1, nullptr, stream);
 }
 
 extern "C" int oriana_dense_col_pass(const oriana_dense *d, const void *imgU, const float *S, float *C, int64_t K,

@@ -66,9 +66,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // overflowed -- the condition under which the shifted form provably reproduces gap.py:74-78.
 constexpr float SUM_LO = -45.0f, SUM_HI = 70.0f, STAT_MAX = 200.0f;
 
-struct PrepLimits { float c_own, half, dead_max; };
+struct PrepLimits { float c_own, half, dead_max, c_other, half_other; };
 __device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stats, int side) {
-    PrepLimits L = {0.0f, SHIFT_MAX, DEAD_MAX};
+    PrepLimits L = {0.0f, SHIFT_MAX, DEAD_MAX, 0.0f, SHIFT_MAX};
     if (stats) {
         // stats = {sum, sum of squares, count} of the row maxima of E[log U] (0..2) and of E[log V] (3..5)
         const float nu = stats[2], nv = stats[5];
@@ -88,6 +88,8 @@ __device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stat
         const float Au = W * share, Av = W - Au;
         L.c_own = side ? qv : qu;
         L.half = side ? Av : Au;
+        L.c_other = side ? qu : qv;
+        L.half_other = side ? Au : Av;
         // a fully masked gene row multiplies exp(lu + lv) by 0: harmless as long as no such exponential overflows
         // against an accepted row of the other side (whose logs stay below c_other + A_other)
         L.dead_max = 85.0f - (side ? qu + Au : qv + Av);
@@ -100,12 +102,25 @@ __device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stat
 // work-group stores its three partial sums, and the group that finishes LAST adds them up in block order and writes
 // the six results -- no float atomics, so the statistics (and with them the choice of path of every row) are the same
 // on every run, and no buffer needs clearing between calls (the last group resets the arrival counter).
-// scratch: [0..5] results {sum, sumsq, count} x {U, V}; [6] arrival counter; [8 + 3 b ...] partials of block b.
+// scratch: [0..5] results {sum, sumsq, count} x {U, V}; [6] arrival counter; [7] the den threshold of the row kernels (below);
+// [8], [9] smallest row maximum of E[log U], E[log V] (over every row with an active, NaN-free entry);
+// [STATS_PART0 + 4 b ...] partials {sum, sumsq, count, min} of block b.
+//
+// [r4] The den threshold.  The row kernels trust s = x / den' of the shifted form when den' >= threshold; below it the entry
+// takes the exact slow path.  What has to hold is that the REFERENCE's own float32 den = exp(mu_i + mv_j) den' is a normal
+// number with room to spare (>= 3e-30, the bound the constant DEN_MIN = 1e-10 gives with the smallest sum the validity test
+// admits, SUM_LO = -45).  The sums of a given pair of factor matrices do not come near SUM_LO in general: every accepted row
+// has mu_i >= max(smallest row maximum, c_u - A_u), likewise mv_j, so with sum_lo the sum of the two bounds the threshold
+// 3e-30 exp(-sum_lo), clamped to [1e-25, DEN_MIN], serves the same guarantee (1e-25: a flagged row's den <= 256 FILL stays
+// below it, and s = x / den' stays far from overflow).  ZI-pCMF at configs[2] drifts along U c, V / c (above): after 25 sweeps
+// the cells' dominant factors sit 25-45 units above the rest and a third of the tiles held entries with den' < 1e-10 --
+// 2.6 ms of slow path per sweep and growing; with sum_lo = +3.5 there the threshold is 1e-25 and none is left.
 constexpr int STATS_MAX_BLOCKS = 1024;                 // per side
+constexpr int STATS_PART0 = 16;
 __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, const float *__restrict__ logU, int64_t n,
                                                    const float *__restrict__ logV, const float *__restrict__ maskV,
-                                                   int64_t m, int K, int nbu, int lane_rows) {
-    __shared__ float bs[4], bq[4], bc[4];
+                                                   int64_t m, int K, int nbu, int lane_rows, int dyn_den) {
+    __shared__ float bs[4], bq[4], bc[4], bm[4];
     __shared__ bool last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool vside = (int)blockIdx.x >= nbu;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
     const float *mask = vside ? maskV : nullptr;
     const int64_t r = vside ? m : n;
     const int64_t b0 = vside ? (int64_t)blockIdx.x - nbu : blockIdx.x, nb = vside ? (int64_t)gridDim.x - nbu : nbu;
-    float sum = 0.f, sq = 0.f, cnt = 0.f;
+    float sum = 0.f, sq = 0.f, cnt = 0.f, mn = INFINITY;
     if (lane_rows) {
         // narrow rows (K <= 32): one LANE per row -- 256 rows per group in flight at once instead of 4
         for (int64_t row = b0 * 256 + threadIdx.x; row < r; row += nb * 256) {
@@ -128,8 +143,9 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
                 if (on) { any_on = true; if (v != v) bad = true; mx = fmaxf(mx, v); }
             }
             if (any_on && !bad && fabsf(mx) <= STAT_MAX) { sum += mx; sq += mx * mx; cnt += 1.f; }
+            if (any_on && !bad) mn = fminf(mn, mx);
         }
-        sum = wave_sum(sum); sq = wave_sum(sq); cnt = wave_sum(cnt);
+        sum = wave_sum(sum); sq = wave_sum(sq); cnt = wave_sum(cnt); mn = -wave_max(-mn);
     } else {
         // one wave per row, FOUR rows of a wave in flight (a wave with one 400-byte read outstanding leaves the pass at
         // 1 TB/s: 0.39 ms for the 400 MB of E[log U] at 1M cells); the rows are accumulated in the order of the plain loop
@@ -158,18 +174,20 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
                 const float m1 = wave_max(mx[u]);
                 const bool b1 = __any(bad[u]), a1 = __any(any_on[u]);
                 if (row0 + u * step < r && a1 && !b1 && fabsf(m1) <= STAT_MAX) { sum += m1; sq += m1 * m1; cnt += 1.f; }
+                if (row0 + u * step < r && a1 && !b1) mn = fminf(mn, m1);
             }
         }
     }
-    if (lane == 0) { bs[w] = sum; bq[w] = sq; bc[w] = cnt; }
+    if (lane == 0) { bs[w] = sum; bq[w] = sq; bc[w] = cnt; bm[w] = mn; }
     __syncthreads();
-    float *part = scratch + 8;
+    float *part = scratch + STATS_PART0;
     unsigned *arrived = (unsigned *)(scratch + 6);
     if (threadIdx.x == 0) {
-        float *pp = part + 3 * (size_t)blockIdx.x;
+        float *pp = part + 4 * (size_t)blockIdx.x;
         __hip_atomic_store(pp + 0, bs[0] + bs[1] + bs[2] + bs[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pp + 1, bq[0] + bq[1] + bq[2] + bq[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pp + 2, bc[0] + bc[1] + bc[2] + bc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 3, fminf(fminf(bm[0], bm[1]), fminf(bm[2], bm[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned old = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last = old + 1 == gridDim.x;
     }
@@ -179,16 +197,27 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
     // a fixed tree -- a fixed summation order
     if (w < 2) {
         const int lo = w ? nbu : 0, hi = w ? (int)gridDim.x : nbu;
-        float a = 0.f, q = 0.f, c = 0.f;
+        float a = 0.f, q = 0.f, c = 0.f, lo_max = INFINITY;
         for (int b = lo + lane; b < hi; b += 64) {
-            a += __hip_atomic_load(part + 3 * (size_t)b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q += __hip_atomic_load(part + 3 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c += __hip_atomic_load(part + 3 * (size_t)b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a += __hip_atomic_load(part + 4 * (size_t)b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q += __hip_atomic_load(part + 4 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c += __hip_atomic_load(part + 4 * (size_t)b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo_max = fminf(lo_max, __hip_atomic_load(part + 4 * (size_t)b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-        a = wave_sum(a); q = wave_sum(q); c = wave_sum(c);
-        if (lane == 0) { scratch[3 * w + 0] = a; scratch[3 * w + 1] = q; scratch[3 * w + 2] = c; }
+        a = wave_sum(a); q = wave_sum(q); c = wave_sum(c); lo_max = -wave_max(-lo_max);
+        if (lane == 0) { scratch[3 * w + 0] = a; scratch[3 * w + 1] = q; scratch[3 * w + 2] = c; scratch[8 + w] = lo_max; }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the den threshold of the row kernels from the statistics just written (see above)
+        const PrepLimits Lu = prep_limits(scratch, 0);
+        const float lo_u = fmaxf(scratch[8], Lu.c_own - Lu.half), lo_v = fmaxf(scratch[9], Lu.c_other - Lu.half_other);
+        float thr = DEN_MIN;
+        const float sum_lo = lo_u + lo_v;
+        if (sum_lo == sum_lo && sum_lo > SUM_LO) thr = fminf(DEN_MIN, fmaxf(3e-30f * expf(-fminf(sum_lo, 80.f)), 1e-25f));
+        scratch[7] = dyn_den ? thr : DEN_MIN;
+        __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // one wave per row
@@ -439,7 +468,9 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                                                    const float *__restrict__ FV, const float *__restrict__ w_nz,
                                                    float *__restrict__ R, float *__restrict__ s_cs,
                                                    float *__restrict__ sw_cs, float *__restrict__ s_rs,
-                                                   int32_t *__restrict__ tile_flag, const float *__restrict__ FV2) {
+                                                   int32_t *__restrict__ tile_flag, const float *__restrict__ FV2,
+                                                   const float *__restrict__ den_min_p) {
+    const float den_min = den_min_p ? *den_min_p : DEN_MIN;   // (see k_row_stats: the den threshold)
     constexpr bool F2I = (VAR & 4) != 0;
     constexpr bool SPARSE = (VAR & 5) != 0, SROW = (VAR & 1) != 0 && !F2I, HASW = (VAR & 2) != 0;
     constexpr int PD = HASW ? 2 : 3;            // prefetch depth (iterations), bounded by the register budget
@@ -558,7 +589,7 @@ __global__ __launch_bounds__(1024) void k_row_pass(oriana_counts cm, const float
                     }                                                                                 \
                     const f2 dd = d01 + d23;                                                          \
                     const float den = group_sum<G>(TAIL ? fmaf(fut, vt, dd.x + dd.y) : dd.x + dd.y);  \
-                    const bool ok = den >= DEN_MIN;          /* false for 0, tiny and NaN */          \
+                    const bool ok = den >= den_min;          /* false for 0, tiny and NaN */          \
                     const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;             \
                     const float sw = HASW ? s * qb_f32<U>(wcur) : s;                                  \
                     const f2 ss = {sw, sw};                                                           \
@@ -1127,7 +1158,9 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
                                                        const float *__restrict__ FV, const float *__restrict__ w_nz,
                                                        float *__restrict__ R, float *__restrict__ s_cs,
                                                        float *__restrict__ sw_cs, float *__restrict__ s_rs,
-                                                       int32_t *__restrict__ tile_flag, oriana_row_split split) {
+                                                       int32_t *__restrict__ tile_flag, oriana_row_split split,
+                                                       const float *__restrict__ den_min_p) {
+    const float den_min = den_min_p ? *den_min_p : DEN_MIN;   // (see k_row_stats: the den threshold)
     constexpr bool SROW = (VAR & 1) != 0, HASW = (VAR & 2) != 0;
     constexpr int KP = 96 + 4 * TAIL, KP4 = KP / 4;
     constexpr int PD = 3;                       // record prefetch depth (iterations)
@@ -1229,7 +1262,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
                 const f2 dd = d01 + d23;                                                              \
                 float den = dd.x + dd.y;                                                              \
                 den += dpp_f32<0xB1>(den);                                                            \
-                const bool ok = den >= DEN_MIN;          /* false for 0, tiny and NaN */              \
+                const bool ok = den >= den_min;          /* false for 0, tiny and NaN */              \
                 const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;                 \
                 const float sw = HASW ? s * pb_f32<U>((U & 1) ? wcur.y : wcur.x) : s;                 \
                 const f2 ss = {sw, sw};                                                               \
@@ -1551,7 +1584,8 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
                                                       float *__restrict__ R, float *__restrict__ s_cs,
                                                       float *__restrict__ sw_cs, float *__restrict__ s_rs,
                                                       int32_t *__restrict__ tile_flag, const float *__restrict__ FV2,
-                                                      oriana_row_split split) {
+                                                      oriana_row_split split, const float *__restrict__ den_min_p) {
+    const float den_min = den_min_p ? *den_min_p : DEN_MIN;   // (see k_row_stats: the den threshold)
     constexpr bool F2I = (VAR & 4) != 0;
     constexpr bool SPARSE = (VAR & 5) != 0, SROW = (VAR & 1) != 0 && !F2I, HASW = (VAR & 2) != 0;
     constexpr int KP = 4 * KP4;
@@ -1658,7 +1692,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
                 const f2 dd = d01 + d23;                                                              \
                 float den = dd.x + dd.y;                                                              \
                 den += dpp_f32<0xB1>(den);                                                            \
-                const bool ok = den >= DEN_MIN;          /* false for 0, tiny and NaN */              \
+                const bool ok = den >= den_min;          /* false for 0, tiny and NaN */              \
                 const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;                 \
                 const float sw = HASW ? s * k100::pb_f32<U>((U & 1) ? wcur.y : wcur.x) : s;           \
                 const f2 ss = {sw, sw};                                                               \
@@ -1895,7 +1929,9 @@ __device__ __forceinline__ int wave_max_i(int v) {
 template <int KP>
 __global__ __launch_bounds__(256) void k_row_pass_narrow(oriana_counts cm, const float *__restrict__ FU,
                                                          const float *__restrict__ FV, float *__restrict__ R,
-                                                         float *__restrict__ s_cs, int32_t *__restrict__ tile_flag) {
+                                                         float *__restrict__ s_cs, int32_t *__restrict__ tile_flag,
+                                                         const float *__restrict__ den_min_p) {
+    const float den_min = den_min_p ? *den_min_p : DEN_MIN;   // (see k_row_stats: the den threshold)
     constexpr int KP4 = Geo<KP>::KP4, ST4 = Geo<KP>::ST4;
     constexpr int PD = 3;                                // record prefetch depth (iterations)
     extern __shared__ f4 lds[];
@@ -1966,7 +2002,7 @@ __global__ __launch_bounds__(256) void k_row_pass_narrow(oriana_counts cm, const
                 }                                                                                     \
                 const f2 dd = d01 + d23;                                                              \
                 const float den = dd.x + dd.y;                                                        \
-                const bool ok = den >= DEN_MIN;              /* false for 0, tiny and NaN */          \
+                const bool ok = den >= den_min;              /* false for 0, tiny and NaN */          \
                 const float s = (ok && valid) ? x * __builtin_amdgcn_rcpf(den) : 0.f;                 \
                 const f2 ss = {s, s};                                                                 \
                 _Pragma("unroll") for (int c = 0; c < KP4; ++c) {                                     \
@@ -2149,6 +2185,11 @@ static bool k64_kernels() {
     static const bool off = [] { const char *e = getenv("ORIANA_PASS_IMPL"); return e && e[0] == 'r' && e[1] >= '1' && e[1] <= '3'; }();
     return !off;
 }
+// ORIANA_DEN_THRESHOLD=fixed: the row kernels keep the constant DEN_MIN (round 3's rule; A/B runs)
+static bool den_threshold_dynamic() {
+    static const bool fixed = [] { const char *e = getenv("ORIANA_DEN_THRESHOLD"); return e && !strcmp(e, "fixed"); }();
+    return !fixed;
+}
 static constexpr bool k64_cfg(int G, int T4, int TAIL) { return G == 4 && 4 * T4 + TAIL >= 9 && 4 * T4 + TAIL <= 16; }
 static bool use_col2(int G, int T4, int TAIL) { return !round1_kernels() && G == 4 && !use_narrow_col(G, T4, TAIL); }   // column pass, two tiles per image
 
@@ -2170,7 +2211,7 @@ static inline size_t lds_bytes(int G, int T4, int TAIL) {
 template <int G, int T4, int TAIL>
 static int launch_row_pass(const oriana_counts *cm, const float *FU, const float *FV, const float *w_nz, float *R,
                            float *s_cs, float *sw_cs, float *s_rs, int32_t *tile_flag, hipStream_t s,
-                           const float *FV2, const oriana_row_split &sp) {
+                           const float *FV2, const oriana_row_split &sp, const float *den_min = nullptr) {
     const int var = (s_rs ? 1 : 0) | (w_nz ? 2 : 0);
     int rc;
     // two-lane kernels: one group per full row block, then the parts of the split ones (row_item)
@@ -2184,7 +2225,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
 #define ORIANA_RP6(V)                                                                                 \
             rc = set_lds(k64::k_row_pass_k64<KP4, V>, lb6);                                           \
             if (rc) return rc;                                                                        \
-            hipLaunchKernelGGL((k64::k_row_pass_k64<KP4, V>), grid6, dim3(512), lb6, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, FV2, sp)
+            hipLaunchKernelGGL((k64::k_row_pass_k64<KP4, V>), grid6, dim3(512), lb6, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, FV2, sp, den_min)
             const int v6 = var | (FV2 ? 4 : 0);
             if (v6 == 0) { ORIANA_RP6(0); }
             else if (v6 == 1) { ORIANA_RP6(1); }
@@ -2210,11 +2251,11 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
         if (w_nz) {
             rc = set_lds(k_row_pass<G, T4, TAIL, 6>, lb2);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, 6>), grid2, block2, lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, FV2);
+            hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, 6>), grid2, block2, lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, FV2, den_min);
         } else {
             rc = set_lds(k_row_pass<G, T4, TAIL, 4>, lb2);
             if (rc) return rc;
-            hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, 4>), grid2, block2, lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, FV2);
+            hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, 4>), grid2, block2, lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, nullptr, tile_flag, FV2, den_min);
         }
         ORIANA_LAUNCH_CHECK();
         return 0;
@@ -2224,7 +2265,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
         if (use_narrow(G, T4, TAIL) && var == 0) {
             constexpr int KP = 4 * G * T4 + G * TAIL;
             hipLaunchKernelGGL((narrow::k_row_pass_narrow<KP>), dim3((unsigned)cm->nrb, (unsigned)gene_splits), dim3(256),
-                               narrow::Geo<KP>::bytes(), s, *cm, FU, FV, R, s_cs, tile_flag);
+                               narrow::Geo<KP>::bytes(), s, *cm, FU, FV, R, s_cs, tile_flag, den_min);
             ORIANA_LAUNCH_CHECK();
             return 0;
         }
@@ -2235,7 +2276,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
 #define ORIANA_RP2(V)                                                                                 \
         rc = set_lds(k100::k_row_pass_k100<TL, V>, lb2);                                              \
         if (rc) return rc;                                                                            \
-        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)items), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, sp)
+        hipLaunchKernelGGL((k100::k_row_pass_k100<TL, V>), dim3((unsigned)items), dim3(512), lb2, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, sp, den_min)
         if (var == 0) { ORIANA_RP2(0); }
         else if (var == 1) { ORIANA_RP2(1); }
         else if (var == 2) { ORIANA_RP2(2); }
@@ -2249,7 +2290,7 @@ static int launch_row_pass(const oriana_counts *cm, const float *FU, const float
 #define ORIANA_RP(V)                                                                                  \
     rc = set_lds(k_row_pass<G, T4, TAIL, V>, lb);                                                           \
     if (rc) return rc;                                                                                \
-    hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, (const float *)nullptr)
+    hipLaunchKernelGGL((k_row_pass<G, T4, TAIL, V>), grid, block, lb, s, *cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, (const float *)nullptr, den_min)
     if (var == 0) { ORIANA_RP(0); }
     else if (var == 1) { ORIANA_RP(1); }
     else if (var == 2) { ORIANA_RP(2); }
@@ -2425,7 +2466,8 @@ extern "C" int oriana_factor_prep(float *F, float *mu, const float *logF, const 
     return 0;
 }
 
-extern "C" int64_t oriana_prep_center_offset(void) { return ((int64_t)sizeof(float) * (8 + 3 * 2 * STATS_MAX_BLOCKS) + 7) / 8 * 8; }
+extern "C" int64_t oriana_prep_center_offset(void) { return ((int64_t)sizeof(float) * (STATS_PART0 + 4 * 2 * STATS_MAX_BLOCKS) + 7) / 8 * 8; }
+extern "C" int64_t oriana_prep_den_threshold_offset(void) { return 7 * (int64_t)sizeof(float); }
 extern "C" int64_t oriana_prep_scratch_bytes(void) { return oriana_prep_center_offset() + 4096; }
 
 extern "C" int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
@@ -2455,7 +2497,7 @@ extern "C" int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *
     const int sbu = capped(n), sbv = capped(m);
     if (sbu + sbv > 0)
         hipLaunchKernelGGL(k_row_stats, dim3((unsigned)(sbu + sbv)), dim3(256), 0, s, scratch, logU, n, logV, maskV, m, (int)K, sbu,
-                           lane_rows);
+                           lane_rows, den_threshold_dynamic() ? 1 : 0);
     const int64_t nbu = (n + 3) / 4, nbv = (m + 3) / 4;
     // zero-fill groups: 16 KB each, at most 4096
     int64_t ncl = (clear_bytes + 16383) / 16384;
@@ -2626,7 +2668,8 @@ extern "C" int oriana_row_pass_masked(const oriana_counts *cm, const float *FU, 
 // tiles of a row block split over gene_splits work-groups, each storing its row sums in its own slab of R.
 extern "C" int oriana_row_pass_general(const oriana_counts *cm, const float *FU, const float *FV, const float *FV2,
                                        const float *w_nz, float *R, float *s_cs, float *sw_cs, float *s_rs,
-                                       int32_t *tile_flag, int64_t K, const oriana_row_split *split, void *stream) {
+                                       int32_t *tile_flag, int64_t K, const oriana_row_split *split, const float *den_min,
+                                       void *stream) {
     if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
     KCfg cfg;
     if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
@@ -2637,7 +2680,7 @@ extern "C" int oriana_row_pass_general(const oriana_counts *cm, const float *FU,
     if (!split_ok(cm, sp)) return ORIANA_EINVAL;
     if (cm->m == 0) FV2 = nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s, FV2, sp)
+#define CALL(G, T, L) return launch_row_pass<G, T, L>(cm, FU, FV, w_nz, R, s_cs, sw_cs, s_rs, tile_flag, s, FV2, sp, den_min)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;

@@ -523,6 +523,7 @@ class ZWorkspace:
         # statistics of the row maxima of E[log U], E[log V] and the partial sums they are built from (zeroed ONCE)
         self.stats = torch.zeros(int(_lib.load().oriana_prep_scratch_bytes()) // 4, **f32)
         self.center_ptr = ptr(self.stats) + int(_lib.load().oriana_prep_center_offset())    # {sum, count} of E[log U] per factor (log sums)
+        self.den_min_ptr = ptr(self.stats) + int(_lib.load().oriana_prep_den_threshold_offset())   # the row kernels' den threshold (float32, device)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
         self._extra = {}
         self._clear_cache = {}
@@ -766,7 +767,7 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
         if ct.ms > 0:
             with _span(ws, 'row_pass'):
                 call('oriana_row_pass_general', ct.sparse_struct, ptr(ws.FU), FVs, None, None, ptr(ws.R), ptr(ws.s_cs), None, None,
-                     ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), st)
+                     ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), ws.den_min_ptr, st)
         if dn is not None:
             with _span(ws, 'dense_images'):
                 call('oriana_dense_images', ptr(ws.dn_imgV), ptr(ws.FV), gd, K, 0, st)
@@ -774,7 +775,7 @@ def zq_gap(ws, Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, phase='all', finalize_row
                 # (the blocks of the chip's last round split as the sliced row pass split them: same rows, same slabs of R)
                 tail = ws.dense_tail(gs)
                 call('oriana_dense_row_pass_tail', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S),
-                     ptr(ws.dn_flag), K, ws.dn_gene_splits, tail[0], tail[1], st)
+                     ptr(ws.dn_flag), K, ws.dn_gene_splits, tail[0], tail[1], ws.den_min_ptr, st)
         with _span(ws, 'fixup'):
             if ct.ms > 0:
                 # (packed Z_hat_j: the sliced part's packed gene 0 is row gd of the buffer)
@@ -873,7 +874,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             if sparse and _FUSE_SPARSE_ROWS:
                 with _span(ws, 'row_pass'):
                     rc = _lib.load().oriana_row_pass_general(cst, ptr(ws.FU), ptr(ws.FV) + goff, ptr(F2) + goff, ptr(w_nz), ptr(ws.R),
-                                                             ptr(ws.s_cs), ptr(sw_cs), None, ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), st)
+                                                             ptr(ws.s_cs), ptr(sw_cs), None, ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), ws.den_min_ptr, st)
                 if rc not in (0, -2):
                     raise _lib.OrianaHipError('oriana_row_pass_general failed with code %d' % rc)
                 fused = rc == 0
@@ -882,7 +883,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
                     ws.s_rs = torch.zeros(max(ct.rslots, 1), dtype=torch.float32, device=ct.device)
                 with _span(ws, 'row_pass'):
                     call('oriana_row_pass_general', cst, ptr(ws.FU), ptr(ws.FV) + goff, None, ptr(w_nz), ptr(ws.R), ptr(ws.s_cs),
-                         ptr(sw_cs), ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), st)
+                         ptr(sw_cs), ptr(ws.s_rs) if sparse else None, ptr(ws.tile_flag), K, ctypes.byref(ws.row_split), ws.den_min_ptr, st)
             if fused or not sparse:
                 nslab = gs                       # (the second row product of the unfused sparse form writes one slab)
             with _span(ws, 'fixup'):
@@ -900,7 +901,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
             with _span(ws, 'dense_row'):
                 tail = ws.dense_tail(nslab)
                 call('oriana_dense_row_pass_tail', dn.c_struct, ptr(ws.FU), ptr(ws.dn_imgV), ptr(ws.R), ptr(ws.dn_S), ptr(ws.dn_flag), K,
-                     ws.dn_gene_splits, tail[0], tail[1], st)
+                     ws.dn_gene_splits, tail[0], tail[1], ws.den_min_ptr, st)
             with _span(ws, 'fixup'):
                 call('oriana_dense_fixup_variant', dn.c_struct, ptr(ws.dn_flag), ptr(ws.dn_S), ptr(log_U_hat), ptr(log_V_hat),
                      ptr(ct.row_perm), ptr(ct.col_perm), ptr(Z_i), ptr(Z_j), ptr(Z_log), ptr(dq), ptr(S_tilde), ptr(S_hat), K, 0, st)

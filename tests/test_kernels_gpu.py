@@ -240,6 +240,43 @@ def test_zq_gap_slow_path(eng):
     _same_zeros(Zj, rZj)
 
 
+@pytest.mark.parametrize('K', [20, 50, 100])
+def test_den_threshold_follows_the_sums(eng, K):
+    """[r4] Factors that have drifted along U c, V / c and specialised (what ZI-pCMF at configs[2] looks like after 25 sweeps):
+    every cell's dominant factor sits 30 above the rest, every gene's 25 above the rest, the sums mu_i + mv_j stay around +15.
+    Wherever the two dominant factors differ the shifted den' is about 1e-11 -- below the worst-case constant 1e-10, far above
+    what the reference's own float32 den needs to be a normal number.  The threshold of the row kernels follows the smallest
+    sum of the inputs at hand: no tile goes down the slow path, and the results are the reference's."""
+    import os
+    if os.environ.get('ORIANA_DEN_THRESHOLD') == 'fixed':
+        pytest.skip('the constant threshold is selected')
+    rng = np.random.default_rng(K)
+    n, m = 300, 280
+    X = _rand_counts(rng, n, m, 0.3)
+    ku, kv = rng.integers(0, K, size=n), rng.integers(0, K, size=m)
+    lu = (5.0 + rng.normal(size=(n, K))).astype(np.float32)
+    lv = (-45.0 + rng.normal(size=(m, K))).astype(np.float32)
+    lu[np.arange(n), ku] += 30.0
+    lv[np.arange(m), kv] += 25.0
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X, lu, lv)
+    thr = float(ws.stats[7])
+    lo = float(lu.max(1).min()) + float(lv.max(1).min())
+    assert 5.0 < lo < 20.0 and thr == np.float32(1e-25)           # 3e-30 exp(-lo) is below the floor
+    assert int(ws.tile_flag.sum().item()) == 0
+    assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
+    # the same factors 60 lower: sums around -45, where the reference's own den runs out of float32 range -- the constant again,
+    # and the entries with differing dominant factors take the exact path
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X, lu - 30.0, lv - 30.0)
+    assert float(ws.stats[7]) == np.float32(1e-10)
+    assert int(ws.tile_flag.sum().item()) > 0
+    assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
+    # in between the threshold is 3e-30 exp(-sum_lo)
+    Zi, Zj, rZi, rZj, ws = _run_gap(eng, X, lu - 25.0, lv - 22.0)
+    lo = float((lu - 25.0).max(1).min()) + float((lv - 22.0).max(1).min())
+    assert abs(float(ws.stats[7]) / (3e-30 * np.exp(-lo)) - 1.0) < 1e-3 and 1e-25 < float(ws.stats[7]) < 1e-10
+    assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
+
+
 def test_zq_gap_rejects_wrong_dtype(eng):
     X = np.ones((4, 4), np.int64)
     ct = eng.CountTiles.from_dense(X, 'cuda')

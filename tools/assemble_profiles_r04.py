@@ -14,7 +14,9 @@ cp = {'bench_c4.json': 'r04_bench_c4.json', 'bench_c4_sliced.json': 'r04_bench_c
       'kernel_stats_c4.csv': 'r04_bench_c4_kernel_stats.csv', 'kernel_stats_c3_zi.csv': 'r04_zigap_c3_kernel_stats.csv',
       'kernel_stats_c5_sparse.csv': 'r04_sparsegap_c5_kernel_stats.csv', 'zigap_gene_count.txt': 'r04_zigap_gene_count.txt',
       'parity_errors.json': 'r04_parity_errors.json', 'bench_c4_norounds.json': 'r04_bench_c4_norounds.json',
-      'bench_c3_zi_norounds.json': 'r04_bench_c3_zi_norounds.json', 'bench_c5_sparse_norounds.json': 'r04_bench_c5_sparse_norounds.json'}
+      'bench_c3_zi_norounds.json': 'r04_bench_c3_zi_norounds.json', 'bench_c5_sparse_norounds.json': 'r04_bench_c5_sparse_norounds.json',
+      'bench_c3_zi_fixedden.json': 'r04_bench_c3_zi_fixedden.json', 'bench_c3_zi_60.json': 'r04_bench_c3_zi_60.json',
+      'bench_c3_zi_60_fixedden.json': 'r04_bench_c3_zi_60_fixedden.json'}
 for a, b in cp.items():
     if os.path.exists(F + a):
         text = open(F + a, 'rb').read()

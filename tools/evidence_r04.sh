@@ -14,6 +14,10 @@ ORIANA_ROW_SPLIT_ROUNDS=off ORIANA_DN_TAIL=off ORIANA_COL_ROUNDS=off timeout 900
 for w in c3_zi c5_sparse; do
   ORIANA_ROW_SPLIT_ROUNDS=off ORIANA_COL_ROUNDS=off timeout 900 python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu > $O/bench_${w}_norounds.json 2>/dev/null
 done
+# the den threshold of the shifted form (DESIGN 10 m): the constant 1e-10 against the bound from the row statistics, 20 and 60 sweeps
+ORIANA_DEN_THRESHOLD=fixed timeout 900 python3 bench.py --workload c3_zi --steps 20 --warmup 5 --no-cpu > $O/bench_c3_zi_fixedden.json 2>/dev/null
+timeout 900 python3 bench.py --workload c3_zi --steps 60 --warmup 5 --no-cpu > $O/bench_c3_zi_60.json 2>/dev/null
+ORIANA_DEN_THRESHOLD=fixed timeout 900 python3 bench.py --workload c3_zi --steps 60 --warmup 5 --no-cpu > $O/bench_c3_zi_60_fixedden.json 2>/dev/null
 for w in c2 c3_zi c5_sparse c4_eighth; do
   timeout 900 python3 bench.py --workload $w --steps 20 --warmup 5 > $O/bench_$w.json 2> $O/bench_$w.err
 done

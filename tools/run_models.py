@@ -12,10 +12,13 @@ a1, b1 = gen.initial_shapes()
 cls = dict(GaP=GaP, ZIGaP=ZIGaP, SparseGaP=SparseGaP, SparseZIGaP=SparseZIGaP)[name]
 model = cls(ct, k=K, init=(a1, b1), device=dev)
 torch.cuda.synchronize(); print('setup %.1fs nnz=%d mem=%.1f GB' % (time.time() - t0, ct.nnz, torch.cuda.max_memory_allocated() / 1e9))
-for it in range(4):
+sweeps = int(os.environ.get('SWEEPS', '4'))           # (long runs: every 10th sweep is printed)
+for it in range(sweeps):
     torch.cuda.synchronize(); t0 = time.time()
     model.step()
-    torch.cuda.synchronize(); print('sweep %d: %.1f ms' % (it, (time.time() - t0) * 1e3))
+    torch.cuda.synchronize()
+    if sweeps <= 8 or it < 3 or it % 10 == 9:
+        print('sweep %d: %.1f ms' % (it, (time.time() - t0) * 1e3))
 st_alpha = model.alpha1.asarray()
 print('alpha1[:4]', st_alpha[:4], 'finite', np.isfinite(st_alpha).all(), 'mem=%.1f GB' % (torch.cuda.max_memory_allocated() / 1e9))
 if hasattr(model, 'pi_d'): print('pi_d mean', float(model.pi_d.tensor.mean()))

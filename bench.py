@@ -266,6 +266,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     stride = 1 if float(n_total) * m >= 2e8 else 4
     sampled = [i for i in range(args.steps) if i % stride == 0]
     marks = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sampled}
+    if world > 1 or odist.sharded():
+        model._xch.timing = True         # events around every blocking exchange: allreduce_exposed_ms
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -280,6 +282,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     barrier()
     elapsed = time.perf_counter() - t0
     model._ws.timer = None
+    exposed_ms = model._xch.exposed_ms() if (world > 1 or odist.sharded()) else None
+    model._xch.timing = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -437,6 +441,9 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
         if world > 1:
             out['per_rank_ms'] = {'columns': ['row_pass', 'col_pass', 'pass'], 'ranks': per_rank}
             out['allreduce_ms'] = allreduce_ms
+            # rank 0's mean wait at the exchange inside the timed sweeps (compute stream reaches the exchange -> last collective
+            # done): what is NOT hidden under the column pass / the dense gene-side kernel
+            out['allreduce_exposed_ms'] = exposed_ms
             out['allreduce_share_of_step'] = allreduce_ms / ms_per_step if ms_per_step > 0 else None
             out['exchange_bytes'] = int(model._xch.numel * 4)
             out['exchange'] = ('one step per sweep: float64 all-reduce of the (small) rate partials, started before the column pass; float32 '
@@ -446,6 +453,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
             out['stateless_binding'] = stateless
         if world == 1 and odist.sharded():
             out['exchange_rehearsal'] = {'backend': dist.get_backend(), 'ranks': 1, 'exchanges': int(model._xch.n_reduces),
+                                         'exposed_ms': exposed_ms,
                                          'collectives': int(model._xch.n_collectives),
                                          'what': 'one-rank process group: every collective of the sharded sweep issued as a self all-reduce'}
         if brief:

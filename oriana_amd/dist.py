@@ -160,6 +160,7 @@ class SweepExchange:
         if self.numel64 and not self._started64:
             bufs.append(self.buf64)
         self._started64 = False
+        ev = self._mark() if not async_op else None
         for b in bufs:
             self.n_collectives += 1
             if async_op:
@@ -168,6 +169,31 @@ class SweepExchange:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.pg)
         if not async_op:
             self.wait()
+            if ev is not None:
+                self._exposed.append((ev, self._mark()))
+
+    # ---- how long the compute stream stood still at the exchange (bench.py: allreduce_exposed_ms) ------------------------
+    timing = False          # set True to bracket every blocking reduce() with events on the current stream
+    _exposed = ()
+
+    def _mark(self):
+        if not self.timing or self.device.type != 'cuda':
+            return None
+        if not isinstance(self._exposed, list):
+            self._exposed = []
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def exposed_ms(self):
+        """Mean time between 'the compute stream reaches the exchange' and 'the last collective of the exchange has completed',
+        over the exchanges since timing was switched on (call after a synchronize): what the sweep waits for -- collectives
+        started earlier (start64, reduce_rows_async) only count with the part that is still outstanding."""
+        pairs = [(a, b) for a, b in self._exposed if a is not None and b is not None]
+        self._exposed = []
+        if not pairs:
+            return None
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
 
     _started64 = False
     _parts32 = False

@@ -291,7 +291,7 @@ def test_bench_self_launch_two_ranks():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
     assert d['config']['collectives_per_sweep'] == 3       # one exchange: float64 rate partials + the two segments of the packed per-gene sums
-    assert len(d['per_rank_ms']['ranks']) == 2 and d['allreduce_ms'] > 0
+    assert len(d['per_rank_ms']['ranks']) == 2 and d['allreduce_ms'] > 0 and d['allreduce_exposed_ms'] >= 0
     assert d['exchange_bytes'] == (30000 * 100 + 4 * 100) * 4
     assert 'K=100' in d['metric'] and '125k' in d['metric']
 
@@ -345,7 +345,7 @@ def test_rccl_single_rank_rehearsal():
     assert d['exchange_rehearsal']['backend'] == 'nccl' and d['exchange_rehearsal']['ranks'] == 1
     # every sweep (1 warm-up + 4 timed + the un-instrumented loop of a launch-bound workload) is one exchange of two
     # collectives (float64 partials started before the column pass, float32 per-gene sums after it)
-    assert d['exchange_rehearsal']['exchanges'] >= 5
+    assert d['exchange_rehearsal']['exchanges'] >= 5 and d['exchange_rehearsal']['exposed_ms'] >= 0
     assert d['exchange_rehearsal']['collectives'] == 2 * d['exchange_rehearsal']['exchanges']      # (c2: sliced layout, one segment)
     assert d['config']['collectives_per_sweep'] == 2
     assert 'exchange_rehearsal' not in out['plain']

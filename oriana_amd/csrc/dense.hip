@@ -164,18 +164,20 @@ __global__ __launch_bounds__(256) void k_scale_factor(float *__restrict__ Fout, 
 // 1.4e-4 on p_s against 2e-6 for the reference's own float32 loop).  a_k = mean of lu_ik over the
 // cells that carry weight (FU_ik > 1e-20 of the row's largest factor, finite log), weighted by the cell's own
 // responsibility sums Z_i[i, k] when they are at hand (the r-weighted mean of lu): acc = {sum w lu, sum w} per factor.
+constexpr int LC_ROWS = 256;
 __global__ __launch_bounds__(256) void k_log_center(double *__restrict__ acc, const float *__restrict__ F,
                                                     const float *__restrict__ logF, const float *__restrict__ W,
                                                     const int32_t *__restrict__ row_index, int64_t r, int K, int Kp) {
-    // thread = (row group, factor): a factor's 1024 / RG rows of the block are summed in registers (coalesced across
-    // the factors), the row groups through LDS, one pair of float64 atomics per factor and block
+    // thread = (row group, factor): a factor's LC_ROWS / RG rows of the block are summed in registers (coalesced across
+    // the factors), the row groups through LDS, one pair of float64 atomics per factor and block.  (256 rows per block:
+    // with 1024 the 500,000 cells of configs[4] were 489 blocks of serial row chains -- 0.33 ms for 384 MB.)
     __shared__ double ssum[256], scnt[256];
     const int Kc = (K <= 64) ? 64 : (K <= 128) ? 128 : 256, RG = 256 / Kc;
     const int k = threadIdx.x % Kc, rg = threadIdx.x / Kc;
     double sum = 0.0, cnt = 0.0;
     if (k < K) {
-        const int64_t r0 = (int64_t)blockIdx.x * 1024;
-        const int64_t r1 = (r0 + 1024 < r) ? r0 + 1024 : r;
+        const int64_t r0 = (int64_t)blockIdx.x * LC_ROWS;
+        const int64_t r1 = (r0 + LC_ROWS < r) ? r0 + LC_ROWS : r;
         for (int64_t row = r0 + rg; row < r1; row += RG) {
             const int64_t src = row_index ? (int64_t)row_index[row] : row;
             const float f = F[row * Kp + k], l = logF[src * K + k];
@@ -377,7 +379,7 @@ extern "C" int oriana_log_center(double *acc, const float *F, const float *logF,
     if (e != hipSuccess) return -1000 - (int)e;
     if (r == 0) return 0;
     if (!F || !logF) return ORIANA_EINVAL;
-    hipLaunchKernelGGL(k_log_center, dim3((unsigned)((r + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, acc, F, logF,
+    hipLaunchKernelGGL(k_log_center, dim3((unsigned)((r + LC_ROWS - 1) / LC_ROWS)), dim3(256), 0, (hipStream_t)stream, acc, F, logF,
                        W, row_index, r, (int)K, (int)Kp);
     ORIANA_LAUNCH_CHECK();
     return 0;

@@ -248,7 +248,7 @@ def test_hybrid_layout_with_a_split_last_round(eng, K, nest):
 
 
 @pytest.mark.parametrize('r,K,perm,nslab', [(1000, 20, True, 1), (257, 100, False, 1), (3, 5, True, 3), (5000, 7, True, 4),
-                                            (40000, 20, False, 1)])
+                                            (40000, 20, False, 1), (40000, 100, True, 1), (33000, 85, False, 3), (33001, 127, True, 2)])
 def test_gamma_update_with_folded_finalize(eng, r, K, perm, nslab):
     """oriana_gamma_update_finalize == oriana_finalize_slabs followed by oriana_gamma_update, bit for bit (both group
     sizes of the update: 1024 threads up to 32768 rows, 256 beyond)."""

@@ -14,7 +14,10 @@ from perf_small import timed                        # noqa: E402
 
 def main():
     dev = 'cuda'
-    for r, K in ((10000, 20), (2000, 20), (125000, 100), (30000, 100), (1000000, 100)):
+    shapes = ((10000, 20), (2000, 20), (125000, 100), (30000, 100), (1000000, 100))
+    if os.environ.get('SHAPES'):                 # e.g. SHAPES=1000000x96,1000000x128
+        shapes = tuple(tuple(int(v) for v in t.split('x')) for t in os.environ['SHAPES'].split(','))
+    for r, K in shapes:
         Kp = engine.kpad(K)
         F = torch.rand(r, Kp, device=dev); R = torch.rand(r, Kp, device=dev) * 50
         Z = torch.zeros(r, K, device=dev)
@@ -34,8 +37,8 @@ def main():
         sL = torch.randn(K, dtype=torch.float64, device=dev) * r
         tm = timed(lambda: call('oriana_mstep_gamma_pair', ptr(q[0]), ptr(q[1]), ptr(sE), ptr(sL), float(r), ptr(q[2]), ptr(q[3]),
                                 ptr(sE), ptr(sL), float(r), ptr(keep), K, st))
-        print('r=%d K=%d rpb=%s lib=%s: gamma_update_finalize %.1f us, mstep pair %.1f us' % (
-            r, K, os.environ.get('ORIANA_GU_RPB', 'auto'), os.path.basename(os.environ.get('ORIANA_HIP_LIB', 'default')), t, tm))
+        print('r=%d K=%d (%.2f TB/s at 44 B per element) rpb=%s lib=%s: gamma_update_finalize %.1f us, mstep pair %.1f us' % (
+            r, K, 44.0 * r * K / (t * 1e-6) / 1e12, os.environ.get('ORIANA_GU_RPB', 'auto'), os.path.basename(os.environ.get('ORIANA_HIP_LIB', 'default')), t, tm))
 
 
 if __name__ == '__main__':

@@ -141,6 +141,16 @@ int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *logU, const
                                   const int32_t *row_index_u, const int32_t *row_index_v,
                                   int64_t n, int64_t m, int64_t K, float *scratch, const oriana_clear_list *clr,
                                   void *stream);
+/* [r5] The cell side prepared by the Gamma update that produced E[log U] (oriana_gamma_update_prep /
+ * oriana_gamma_update_finalize_prep below: FU holds exp(E[log U] - row maximum) of every row, mu_u [n] the row maxima (NaN: the
+ * row holds a NaN), upart [4 * nupart] the per-group partial statistics of the maxima): this call combines the statistics,
+ * prepares the gene side from logV, overwrites the cell rows the centred validity test rejects, and zero-fills `clr` -- the
+ * 2 x 4 K n bytes of reading E[log U] twice (statistics, preparation) and the second write of FU disappear from the sweep
+ * (0.9 ms of 2.9 ms outside the passes at 1M x 30k, K = 100).  Same F and same statistics as oriana_factor_prep_pair up to the
+ * summation order of the partials. */
+int oriana_factor_prep_pair_fused(float *FU, const float *mu_u, const float *upart, int64_t nupart, float *FV,
+                                  const float *logV, const float *maskV, const int32_t *row_index_v,
+                                  int64_t n, int64_t m, int64_t K, float *scratch, const oriana_clear_list *clr, void *stream);
 int64_t oriana_prep_scratch_bytes(void);   /* includes 4096 bytes for the log-sum centres at oriana_prep_center_offset() */
 int64_t oriana_prep_center_offset(void);
 
@@ -438,6 +448,26 @@ int oriana_gamma_update_finalize_from(double *a1, double *a2, double *E, float *
                                  const double *prior1, const double *prior2,
                                  float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
                                  const double *rate_vec, int64_t r, int64_t K, void *stream);
+
+/* [r5] Both updates with the cell-side half of the NEXT sweep's factor preparation folded in (FU_next != NULL; see
+ * oriana_factor_prep_pair_fused): FU_next (r, Kp) float32, zero-filled once by the caller (padding columns are never written),
+ * gets exp(Elog - row maximum) in the packed row order of F / R (finalize form) or in the caller's row order (plain form: only
+ * for counts without a row permutation); mu_out [r]; upart [4 * oriana_gamma_update_prep_blocks(r, K)].  The blocks query
+ * returns 0 when no vector kernel serves this K (odd K above 64, K above 256): the caller then keeps the separate preparation.
+ * FU_next = NULL: exactly oriana_gamma_update / oriana_gamma_update_finalize_from. */
+int64_t oriana_gamma_update_prep_blocks(int64_t r, int64_t K);
+int oriana_gamma_update_prep(double *a1, double *a2, double *E, float *Elog,
+                             double *colsum_E, double *colsum_Elog,
+                             const double *prior1, const double *prior2,
+                             const float *Z, const float *zmul,
+                             const double *rate_vec, const double *rate_mat, const float *rmul,
+                             int64_t r, int64_t K, float *FU_next, float *mu_out, float *upart, void *stream);
+int oriana_gamma_update_finalize_prep(double *a1, double *a2, double *E, float *Elog,
+                                 double *colsum_E, double *colsum_Elog,
+                                 const double *prior1, const double *prior2,
+                                 float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
+                                 const double *rate_vec, int64_t r, int64_t K, float *FU_next, float *mu_out, float *upart,
+                                 void *stream);
 
 /* M-step for one Gamma node (gap.py:117-129; utils.py:39-51):
  *   p1 = max(1e-15, nan_to_num(inverse_digamma(log(p2) + f32(colsum_Elog / count))))

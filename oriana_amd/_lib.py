@@ -50,6 +50,7 @@ _SIGS = {
     'oriana_factor_prep': (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
     'oriana_factor_prep_pair': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'oriana_factor_prep_pair_clear': (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, ctypes.POINTER(OrianaClearList), _P]),
+    'oriana_factor_prep_pair_fused': (c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, ctypes.POINTER(OrianaClearList), _P]),
     'oriana_prep_scratch_bytes': (_I, []),
     'oriana_row_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'oriana_row_pass_gene_splits': (_I, [ctypes.POINTER(OrianaCounts), _I]),
@@ -90,6 +91,9 @@ _SIGS = {
     'oriana_mstep_gamma': (c_int, [_P, _P, _P, _P, c_double, _I, _P]),
     'oriana_gamma_update_finalize': (c_int, [_P] * 11 + [_I, _P, _P, _I, _I, _P]),
     'oriana_gamma_update_finalize_from': (c_int, [_P] * 11 + [_I, _I, _P, _P, _I, _I, _P]),
+    'oriana_gamma_update_prep_blocks': (_I, [_I, _I]),
+    'oriana_gamma_update_prep': (c_int, [_P] * 13 + [_I, _I, _P, _P, _P, _P]),
+    'oriana_gamma_update_finalize_prep': (c_int, [_P] * 11 + [_I, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     'oriana_mstep_gamma_pair': (c_int, [_P, _P, _P, _P, c_double, _P, _P, _P, _P, c_double, _P, _I, _P]),
     'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),
     'oriana_dropout_update': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

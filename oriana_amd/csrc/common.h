@@ -24,6 +24,7 @@ constexpr int TILE = ORIANA_TILE;          // 256 x 256 count tiles
 constexpr float DEN_MIN = 1e-10f;          // below this the shifted softmax denominator is not trusted
 constexpr float SHIFT_MAX = 22.0f;         // |row shift| above this -> exact slow path for the row
 constexpr float FILL = 1e-30f;             // factor value of such rows: den <= 256 * 1e-30 < DEN_MIN, but never 0
+constexpr float STAT_MAX = 200.0f;        // row maxima beyond +-this are left out of the statistics of the centred validity test (passes.hip)
 constexpr float DEAD_MAX = 40.0f;          // logs of a fully masked row below this: exp(lu + lv) cannot overflow (22 + 40 < 88)
 
 // ---- DPP cross-lane moves (wave64; no LDS traffic) ------------------------------------------

@@ -64,7 +64,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // mu_i + mv_j = (mu_i - cu) + (mv_j - cv) + (cu + cv) stays inside (SUM_LO, SUM_HI): there the reference's own
 // float32 den = exp(mu_i + mv_j) den' lies in [3e-30, 3e32] and none of its terms that matter is denormal or
 // overflowed -- the condition under which the shifted form provably reproduces gap.py:74-78.
-constexpr float SUM_LO = -45.0f, SUM_HI = 70.0f, STAT_MAX = 200.0f;
+constexpr float SUM_LO = -45.0f, SUM_HI = 70.0f;        // (STAT_MAX: common.h)
 
 struct PrepLimits { float c_own, half, dead_max, c_other, half_other; };
 __device__ __forceinline__ PrepLimits prep_limits(const float *__restrict__ stats, int side) {
@@ -119,7 +119,10 @@ constexpr int STATS_MAX_BLOCKS = 1024;                 // per side
 constexpr int STATS_PART0 = 16;
 __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, const float *__restrict__ logU, int64_t n,
                                                    const float *__restrict__ logV, const float *__restrict__ maskV,
-                                                   int64_t m, int K, int nbu, int lane_rows, int dyn_den) {
+                                                   int64_t m, int K, int nbu, int lane_rows, int dyn_den,
+                                                   const float *__restrict__ upart, int nupart) {
+    // [r5] upart != NULL (then nbu == 0): the partials of side U were left by the cell-side Gamma update that produced
+    // E[log U] (k_gamma_update_vec, PREP outputs: nupart groups x {sum, sumsq, count, min}); this launch covers side V only
     __shared__ float bs[4], bq[4], bc[4], bm[4];
     __shared__ bool last;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -196,13 +199,15 @@ __global__ __launch_bounds__(256) void k_row_stats(float *__restrict__ scratch, 
     // the last group: waves 0 / 1 add up the partials of side U / V, each lane its blocks in order, then the lanes in
     // a fixed tree -- a fixed summation order
     if (w < 2) {
-        const int lo = w ? nbu : 0, hi = w ? (int)gridDim.x : nbu;
+        const bool ext = w == 0 && upart != nullptr;
+        const float *src = ext ? upart : part;
+        const int lo = ext ? 0 : (w ? nbu : 0), hi = ext ? nupart : (w ? (int)gridDim.x : nbu);
         float a = 0.f, q = 0.f, c = 0.f, lo_max = INFINITY;
         for (int b = lo + lane; b < hi; b += 64) {
-            a += __hip_atomic_load(part + 4 * (size_t)b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q += __hip_atomic_load(part + 4 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c += __hip_atomic_load(part + 4 * (size_t)b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lo_max = fminf(lo_max, __hip_atomic_load(part + 4 * (size_t)b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            a += __hip_atomic_load(src + 4 * (size_t)b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q += __hip_atomic_load(src + 4 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c += __hip_atomic_load(src + 4 * (size_t)b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo_max = fminf(lo_max, __hip_atomic_load(src + 4 * (size_t)b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         a = wave_sum(a); q = wave_sum(q); c = wave_sum(c); lo_max = -wave_max(-lo_max);
         if (lane == 0) { scratch[3 * w + 0] = a; scratch[3 * w + 1] = q; scratch[3 * w + 2] = c; scratch[8 + w] = lo_max; }
@@ -285,8 +290,26 @@ __global__ __launch_bounds__(256) void k_factor_prep_pair(float *__restrict__ FU
                                                           const float *__restrict__ maskV,
                                                           const int32_t *__restrict__ riu, const int32_t *__restrict__ riv,
                                                           int64_t n, int64_t m, int K, int Kp, int nbu, int nbv,
-                                                          const float *__restrict__ stats, oriana_clear_list clr) {
-    if ((int)blockIdx.x < nbu) { factor_prep_row(FU, nullptr, logU, nullptr, riu, n, K, Kp, stats, 0, blockIdx.x); return; }
+                                                          const float *__restrict__ stats, oriana_clear_list clr,
+                                                          const float *__restrict__ mu_u) {
+    if ((int)blockIdx.x < nbu) {
+        if (mu_u) {
+            // [r5] FU was written by the Gamma update that produced E[log U] (row maxima in mu_u, NaN = the row holds a NaN):
+            // only the validity test is left, which needs the statistics of all rows -- one LANE per row, a rejected row is
+            // overwritten with the constant of factor_prep_row
+            const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+            if (row >= n) return;
+            const PrepLimits lim = prep_limits(stats, 0);
+            const float mx = mu_u[row];
+            if (!(fabsf(mx - lim.c_own) < lim.half)) {
+                float *f = FU + row * Kp;
+                for (int k = 0; k < K; ++k) f[k] = FILL;
+            }
+            return;
+        }
+        factor_prep_row(FU, nullptr, logU, nullptr, riu, n, K, Kp, stats, 0, blockIdx.x);
+        return;
+    }
     if ((int)blockIdx.x < nbu + nbv) { factor_prep_row(FV, nullptr, logV, maskV, riv, m, K, Kp, stats, 1, (int64_t)blockIdx.x - nbu); return; }
     const int64_t cb = (int64_t)blockIdx.x - nbu - nbv, ncl = (int64_t)gridDim.x - nbu - nbv;
     #pragma unroll 1
@@ -2470,10 +2493,12 @@ extern "C" int64_t oriana_prep_center_offset(void) { return ((int64_t)sizeof(flo
 extern "C" int64_t oriana_prep_den_threshold_offset(void) { return 7 * (int64_t)sizeof(float); }
 extern "C" int64_t oriana_prep_scratch_bytes(void) { return oriana_prep_center_offset() + 4096; }
 
-extern "C" int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
-                                             const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
-                                             int64_t K, float *scratch, const oriana_clear_list *clr, void *stream) {
+static int factor_prep_pair_impl(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                                 const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
+                                 int64_t K, float *scratch, const oriana_clear_list *clr, const float *mu_u,
+                                 const float *upart, int64_t nupart, void *stream) {
     const int64_t Kp = oriana_kpad(K);
+    const bool fused = mu_u != nullptr;
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (Kp == 0) return ORIANA_EKRANGE;
     oriana_clear_list cl;
@@ -2487,26 +2512,41 @@ extern "C" int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *
         }
     }
     if (n == 0 && m == 0 && clear_bytes == 0) return 0;
-    if ((n > 0 && (!FU || !logU)) || (m > 0 && (!FV || !logV)) || !scratch) return ORIANA_EINVAL;
+    if ((n > 0 && (!FU || (!fused && !logU))) || (m > 0 && (!FV || !logV)) || !scratch) return ORIANA_EINVAL;
+    if (fused && (!upart || nupart <= 0 || nupart > 0x7fffffffLL || n <= 0)) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // (one work-group per 64 rows, at most STATS_MAX_BLOCKS per side: every group ends with an agent-scope
     //  release / acquire pair, which on a small matrix costs more than the rows it covers)
     const int lane_rows = K <= 32 ? 1 : 0;
     const int64_t rows_per_group = lane_rows ? 256 : 64;
     auto capped = [&](int64_t r) { const int64_t b = (r + rows_per_group - 1) / rows_per_group; return (int)(b < STATS_MAX_BLOCKS ? b : STATS_MAX_BLOCKS); };
-    const int sbu = capped(n), sbv = capped(m);
+    const int sbu = fused ? 0 : capped(n);
+    const int sbv = (fused && m == 0) ? 1 : capped(m);      // (fused: some group has to combine the cell side's partials)
     if (sbu + sbv > 0)
         hipLaunchKernelGGL(k_row_stats, dim3((unsigned)(sbu + sbv)), dim3(256), 0, s, scratch, logU, n, logV, maskV, m, (int)K, sbu,
-                           lane_rows, den_threshold_dynamic() ? 1 : 0);
-    const int64_t nbu = (n + 3) / 4, nbv = (m + 3) / 4;
+                           lane_rows, den_threshold_dynamic() ? 1 : 0, fused ? upart : (const float *)nullptr, (int)nupart);
+    const int64_t nbu = fused ? (n + 255) / 256 : (n + 3) / 4, nbv = (m + 3) / 4;
     // zero-fill groups: 16 KB each, at most 4096
     int64_t ncl = (clear_bytes + 16383) / 16384;
     if (ncl > 4096) ncl = 4096;
     if (nbu + nbv + ncl > 0x7fffffffLL) return ORIANA_EINVAL;
     hipLaunchKernelGGL(k_factor_prep_pair, dim3((unsigned)(nbu + nbv + ncl)), dim3(256), 0, s, FU, FV, logU, logV, maskV,
-                       row_index_u, row_index_v, n, m, (int)K, (int)Kp, (int)nbu, (int)nbv, (const float *)scratch, cl);
+                       row_index_u, row_index_v, n, m, (int)K, (int)Kp, (int)nbu, (int)nbv, (const float *)scratch, cl, mu_u);
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_factor_prep_pair_clear(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,
+                                             const int32_t *row_index_u, const int32_t *row_index_v, int64_t n, int64_t m,
+                                             int64_t K, float *scratch, const oriana_clear_list *clr, void *stream) {
+    return factor_prep_pair_impl(FU, FV, logU, logV, maskV, row_index_u, row_index_v, n, m, K, scratch, clr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int oriana_factor_prep_pair_fused(float *FU, const float *mu_u, const float *upart, int64_t nupart, float *FV,
+                                             const float *logV, const float *maskV, const int32_t *row_index_v, int64_t n,
+                                             int64_t m, int64_t K, float *scratch, const oriana_clear_list *clr, void *stream) {
+    if (!mu_u) return ORIANA_EINVAL;
+    return factor_prep_pair_impl(FU, FV, nullptr, logV, maskV, nullptr, row_index_v, n, m, K, scratch, clr, mu_u, upart, nupart, stream);
 }
 
 extern "C" int oriana_factor_prep_pair(float *FU, float *FV, const float *logU, const float *logV, const float *maskV,

@@ -7,6 +7,7 @@
 // fused so that each parameter matrix is written once and Z is read once.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace oriana {
 
@@ -120,6 +121,230 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
             if (colsum_E && tE == 1.2345) colsum_E[k] = tL;
 #endif
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// [r5] The same update, VEC consecutive factors per lane and LPR lanes per row (a power of two >= K / VEC; 64 / LPR rows
+// per wave and iteration): every access is a 4 * VEC (float32) or 8 * VEC (float64) byte piece per lane, the pieces of a row
+// contiguous -- round 4's kernel gave each lane ONE element per row (512- and 288-byte wave stores at K = 100 that
+// straddle the 128-byte lines: 2.3 TB/s for 4.4 GB).  Needs K % VEC == 0 (row starts stay aligned).
+//
+// PREP outputs (FUn != NULL), the cell-side half of the NEXT sweep's factor preparation: the row's K values of E[log .] are in
+// the row's LPR lanes anyway, so the row maximum, F = exp(E[log .] - max) and the per-group partial statistics of the maxima
+// (k_row_stats) cost no extra read: FUn (r, Kp) gets the row in the arithmetic of factor_prep_row (padding columns are never
+// written: the buffer is zero-filled once), mu_out[r] the maximum (NaN if the row holds a NaN), upart[4 b ..] = {sum, sum of
+// squares, count, min} of group b's maxima.  The validity test needs the statistics of ALL rows, i.e. the end of this
+// launch: the next sweep's preparation applies it to mu_out and overwrites the rejected rows (k_factor_prep_pair, fix mode).
+struct GuVecArgs {
+    double *a1, *a2, *E;
+    float *Elog;
+    double *colsum_E, *colsum_Elog;
+    const double *prior1, *prior2;
+    const float *Z_in, *zmul;
+    const double *rate_vec, *rate_mat;
+    const float *rmul;
+    int64_t r;
+    int K, rpb;
+    float *Zfin;
+    const float *F, *Rs;
+    const int32_t *row_index;
+    int Kp, nslab;
+    int64_t slab_row0;
+    float *FUn, *mu_out, *upart;
+};
+
+template <int VEC> struct VecF;
+template <> struct VecF<1> { typedef float T; };
+template <> struct VecF<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct VecF<4> { typedef float T __attribute__((ext_vector_type(4))); };
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int VEC>
+__device__ __forceinline__ void ld_f32(float (&o)[VEC], const float *p) {
+    typedef typename VecF<VEC>::T V;
+    const V v = *reinterpret_cast<const V *>(p);
+    if constexpr (VEC == 1) o[0] = v;
+    else { _Pragma("unroll") for (int i = 0; i < VEC; ++i) o[i] = v[i]; }
+}
+template <int VEC>
+__device__ __forceinline__ void st_f32(float *p, const float (&o)[VEC]) {
+    typedef typename VecF<VEC>::T V;
+    V v;
+    if constexpr (VEC == 1) v = o[0];
+    else { _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = o[i]; }
+    *reinterpret_cast<V *>(p) = v;
+}
+template <int VEC>
+__device__ __forceinline__ void ld_f64(double (&o)[VEC], const double *p) {
+    if constexpr (VEC == 1) o[0] = *p;
+    else { _Pragma("unroll") for (int i = 0; i < VEC; i += 2) { const d2 v = *reinterpret_cast<const d2 *>(p + i); o[i] = v[0]; o[i + 1] = v[1]; } }
+}
+template <int VEC>
+__device__ __forceinline__ void st_f64(double *p, const double (&o)[VEC]) {
+    if constexpr (VEC == 1) *p = o[0];
+    else { _Pragma("unroll") for (int i = 0; i < VEC; i += 2) { d2 v; v[0] = o[i]; v[1] = o[i + 1]; *reinterpret_cast<d2 *>(p + i) = v; } }
+}
+
+// gamma_meanlog_f32 with logf(f32(a2)) given (the pCMF cell / gene side: a2 is one value per factor)
+__device__ __forceinline__ float gamma_meanlog_f32_lg(double a1, float lg) {
+    const float a1f = (float)a1;
+    float psi;
+    if (a1f > 0.0f && a1f < INFINITY) psi = (float)digamma_pos_for_f32((double)a1f);
+    else psi = (float)digamma_f64((double)a1f);
+    return psi - lg;
+}
+
+template <bool FIN, int VEC, int LPR>
+__global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
+    constexpr int RPW = 64 / LPR, NW = 4, NCOL = LPR * VEC;
+    __shared__ double red[2][NW][NCOL];
+    __shared__ float sred[4][NW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cg = lane & (LPR - 1), sr = lane / LPR;
+    const int k0 = cg * VEC, K = A.K, Kp = A.Kp;
+    const bool act = k0 < K;
+    const int64_t r = A.r;
+    const int64_t r0 = (int64_t)blockIdx.x * A.rpb;
+    const int64_t r1 = (r0 + A.rpb < r) ? r0 + A.rpb : r;
+    const bool prep = A.FUn != nullptr;
+    const bool upd = FIN || A.Z_in != nullptr;
+    double p1[VEC], p2[VEC], rv[VEC], s2c[VEC], sE[VEC], sL[VEC];
+    float lg2c[VEC];
+    #pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        p1[v] = (act && upd) ? A.prior1[k0 + v] : 1.0;
+        p2[v] = (act && upd) ? A.prior2[k0 + v] : 1.0;
+        rv[v] = (act && A.rate_vec) ? A.rate_vec[k0 + v] : 0.0;
+        s2c[v] = clamp_eps(p2[v] + rv[v]);
+        lg2c[v] = logf((float)s2c[v]);
+        sE[v] = 0.0; sL[v] = 0.0;
+    }
+    float st_sum = 0.f, st_sq = 0.f, st_cnt = 0.f, st_min = INFINITY;
+    for (int64_t rb = r0 + w * RPW; rb < r1; rb += NW * RPW) {
+        const int64_t row = rb + sr;
+        const bool in = act && row < r1;
+        float el[VEC];
+        #pragma unroll
+        for (int v = 0; v < VEC; ++v) el[v] = -INFINITY;
+        if (in) {
+            const int64_t orow = (FIN && A.row_index) ? (int64_t)A.row_index[row] : row;
+            const int64_t idx = orow * K + k0;
+            double s1[VEC], s2[VEC], e[VEC];
+            if (FIN) {
+                float rr[VEC], f[VEC], z[VEC];
+                ld_f32<VEC>(rr, A.Rs + row * Kp + k0);
+                ld_f32<VEC>(f, A.F + row * Kp + k0);
+                ld_f32<VEC>(z, A.Zfin + idx);
+                const int ns = row >= A.slab_row0 ? A.nslab : 1;
+                for (int sl = 1; sl < ns; ++sl) {
+                    float r2[VEC];
+                    ld_f32<VEC>(r2, A.Rs + ((int64_t)sl * r + row) * Kp + k0);
+                    #pragma unroll
+                    for (int v = 0; v < VEC; ++v) rr[v] += r2[v];
+                }
+                #pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    z[v] = fmaf(f[v], rr[v], z[v]) + 0.0f;                                  // k_finalize (accumulate)
+                    s1[v] = clamp_eps(p1[v] + (double)z[v]);
+                    s2[v] = s2c[v];
+                }
+                st_f32<VEC>(A.Zfin + idx, z);
+                st_f64<VEC>(A.a1 + idx, s1);
+                st_f64<VEC>(A.a2 + idx, s2);
+                #pragma unroll
+                for (int v = 0; v < VEC; ++v) el[v] = gamma_meanlog_f32_lg(s1[v], lg2c[v]);
+            } else if (A.Z_in) {
+                float z[VEC];
+                ld_f32<VEC>(z, A.Z_in + idx);
+                if (A.zmul) {
+                    float zm[VEC];
+                    ld_f32<VEC>(zm, A.zmul + idx);
+                    #pragma unroll
+                    for (int v = 0; v < VEC; ++v) z[v] = zm[v] * z[v];                        // f32 product, as S_hat * Z_hat_j
+                }
+                double rt[VEC];
+                if (A.rate_mat) ld_f64<VEC>(rt, A.rate_mat + idx);
+                else { _Pragma("unroll") for (int v = 0; v < VEC; ++v) rt[v] = rv[v]; }
+                if (A.rmul) {
+                    float rm[VEC];
+                    ld_f32<VEC>(rm, A.rmul + idx);
+                    #pragma unroll
+                    for (int v = 0; v < VEC; ++v) rt[v] = (double)rm[v] * rt[v];
+                }
+                #pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    s1[v] = clamp_eps(p1[v] + (double)z[v]);
+                    s2[v] = clamp_eps(p2[v] + rt[v]);
+                }
+                st_f64<VEC>(A.a1 + idx, s1);
+                st_f64<VEC>(A.a2 + idx, s2);
+                #pragma unroll
+                for (int v = 0; v < VEC; ++v) el[v] = gamma_meanlog_f32(s1[v], s2[v]);
+            } else {
+                ld_f64<VEC>(s1, A.a1 + idx);
+                ld_f64<VEC>(s2, A.a2 + idx);
+                #pragma unroll
+                for (int v = 0; v < VEC; ++v) el[v] = gamma_meanlog_f32(s1[v], s2[v]);
+            }
+            #pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                e[v] = s1[v] / s2[v];                                                       // gamma.py:37-46
+                sE[v] += e[v];
+                sL[v] += (double)el[v];
+            }
+            st_f64<VEC>(A.E + idx, e);
+            st_f32<VEC>(A.Elog + idx, el);
+        }
+        if (prep) {
+            // (wave-uniform: every lane takes part in the row's reduction; lanes beyond K or beyond the last row hold -inf)
+            float mx = -INFINITY;
+            bool bad = false;
+            #pragma unroll
+            for (int v = 0; v < VEC; ++v) { if (el[v] != el[v]) bad = true; mx = fmaxf(mx, el[v]); }
+            int badi = bad ? 1 : 0;
+            #pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); badi |= __shfl_xor(badi, o, 64); }
+            if (in) {
+                float fu[VEC];
+                #pragma unroll
+                for (int v = 0; v < VEC; ++v) fu[v] = (float)exp((double)el[v] - (double)mx);
+                st_f32<VEC>(A.FUn + row * Kp + k0, fu);
+                if (cg == 0) {
+                    A.mu_out[row] = badi ? NAN : mx;
+                    if (!badi) {
+                        if (fabsf(mx) <= STAT_MAX) { st_sum += mx; st_sq += mx * mx; st_cnt += 1.f; }          // as k_row_stats
+                        st_min = fminf(st_min, mx);
+                    }
+                }
+            }
+        }
+    }
+    // column sums: lanes holding the same factors inside the wave, then the four waves through LDS
+    #pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        double vE = sE[v], vL = sL[v];
+        #pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) { vE += __shfl_xor(vE, o, 64); vL += __shfl_xor(vL, o, 64); }
+        if (sr == 0) { red[0][w][k0 + v] = vE; red[1][w][k0 + v] = vL; }
+    }
+    if (prep) {
+        st_sum = wave_sum(st_sum); st_sq = wave_sum(st_sq); st_cnt = wave_sum(st_cnt); st_min = -wave_max(-st_min);
+        if (lane == 0) { sred[0][w] = st_sum; sred[1][w] = st_sq; sred[2][w] = st_cnt; sred[3][w] = st_min; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const double tE = ((red[0][0][k] + red[0][1][k]) + red[0][2][k]) + red[0][3][k];
+        const double tL = ((red[1][0][k] + red[1][1][k]) + red[1][2][k]) + red[1][3][k];
+        if (A.colsum_E) atomicAdd(&A.colsum_E[k], tE);
+        if (A.colsum_Elog) atomicAdd(&A.colsum_Elog[k], tL);
+    }
+    if (prep && threadIdx.x == 0) {
+        float *pp = A.upart + 4 * (size_t)blockIdx.x;
+        pp[0] = ((sred[0][0] + sred[0][1]) + sred[0][2]) + sred[0][3];
+        pp[1] = ((sred[1][0] + sred[1][1]) + sred[1][2]) + sred[1][3];
+        pp[2] = ((sred[2][0] + sred[2][1]) + sred[2][2]) + sred[2][3];
+        pp[3] = fminf(fminf(sred[3][0], sred[3][1]), fminf(sred[3][2], sred[3][3]));
     }
 }
 
@@ -241,19 +466,88 @@ static inline bool gu_large_groups(int64_t r) {
     return r > 4096 && r <= 32768;
 }
 
+
+// ---- dispatch of k_gamma_update_vec -------------------------------------------------------------------------------
+static inline bool aligned_to(const void *p, uintptr_t a) { return p == nullptr || ((uintptr_t)p & (a - 1)) == 0; }
+
+// VEC and LPR for this K (false: the element-per-lane kernel serves it)
+static inline bool gu_vec_cfg(int64_t K, bool wide_ok, int *vec, int *lpr) {
+    int v;
+    if (wide_ok && K % 4 == 0 && K <= 256) v = 4;
+    else if (wide_ok && K % 2 == 0 && K <= 128) v = 2;
+    else if (K <= 64) v = 1;
+    else return false;
+    int l = 8;
+    while (l * v < K) l <<= 1;
+    *vec = v; *lpr = l;
+    return true;
+}
+
+static inline int gu_vec_rpb(int64_t r, int lpr) {
+    const int ry = 4 * (64 / lpr);
+    return rows_per_block(r, ry);
+}
+
+template <bool FIN, int VEC>
+static void gu_vec_launch_lpr(const GuVecArgs &a, int lpr, int64_t nblk, hipStream_t s) {
+    const dim3 g((unsigned)nblk), b(256);
+    switch (lpr) {
+    case 8: hipLaunchKernelGGL((k_gamma_update_vec<FIN, VEC, 8>), g, b, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_gamma_update_vec<FIN, VEC, 16>), g, b, 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_gamma_update_vec<FIN, VEC, 32>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_gamma_update_vec<FIN, VEC, 64>), g, b, 0, s, a); break;
+    }
+}
+
+// true: launched (a.rpb is set here); false: no vector configuration for this K / these pointers
+template <bool FIN>
+static bool gu_vec_launch(GuVecArgs a, hipStream_t s) {
+    const bool wide_ok = aligned_to(a.a1, 16) && aligned_to(a.a2, 16) && aligned_to(a.E, 16) && aligned_to(a.Elog, 16) &&
+                         aligned_to(a.Z_in, 16) && aligned_to(a.zmul, 16) && aligned_to(a.rate_mat, 16) && aligned_to(a.rmul, 16) &&
+                         aligned_to(a.Zfin, 16) && aligned_to(a.F, 16) && aligned_to(a.Rs, 16) && aligned_to(a.FUn, 16);
+    int vec, lpr;
+    if (!gu_vec_cfg(a.K, wide_ok, &vec, &lpr)) return false;
+    a.rpb = gu_vec_rpb(a.r, lpr);
+    const int64_t nblk = (a.r + a.rpb - 1) / a.rpb;
+    if (vec == 4) gu_vec_launch_lpr<FIN, 4>(a, lpr, nblk, s);
+    else if (vec == 2) gu_vec_launch_lpr<FIN, 2>(a, lpr, nblk, s);
+    else gu_vec_launch_lpr<FIN, 1>(a, lpr, nblk, s);
+    return true;
+}
+
+static inline bool gu_scalar_forced() {
+    static const bool f = [] { const char *e = getenv("ORIANA_GU_KERNEL"); return e && !strcmp(e, "r4"); }();   // A/B runs
+    return f;
+}
+
 }  // namespace oriana
 
 using namespace oriana;
 
-extern "C" int oriana_gamma_update(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
-                                   double *colsum_Elog, const double *prior1, const double *prior2, const float *Z,
-                                   const float *zmul, const double *rate_vec, const double *rate_mat,
-                                   const float *rmul, int64_t r, int64_t K, void *stream) {
+extern "C" int64_t oriana_gamma_update_prep_blocks(int64_t r, int64_t K) {
+    int vec, lpr;
+    if (r <= 0 || K <= 0 || gu_scalar_forced() || !gu_vec_cfg(K, true, &vec, &lpr)) return 0;
+    const int rpb = gu_vec_rpb(r, lpr);
+    return (r + rpb - 1) / rpb;
+}
+
+extern "C" int oriana_gamma_update_prep(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+                                        double *colsum_Elog, const double *prior1, const double *prior2, const float *Z,
+                                        const float *zmul, const double *rate_vec, const double *rate_mat,
+                                        const float *rmul, int64_t r, int64_t K, float *FU_next, float *mu_out, float *upart,
+                                        void *stream) {
     if (r < 0 || K <= 0) return ORIANA_EINVAL;
     if (K > 128 * GU_MAXCOLS_PER_THREAD) return ORIANA_EKRANGE;
     if (r == 0) return 0;
     if (!a1 || !a2 || !E || !Elog) return ORIANA_EINVAL;
     if (Z && (!prior1 || !prior2 || (!rate_vec && !rate_mat))) return ORIANA_EINVAL;
+    if (FU_next && (!mu_out || !upart || oriana_kpad(K) == 0)) return ORIANA_EINVAL;
+    if (!gu_scalar_forced()) {
+        GuVecArgs a = {a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, 0,
+                       nullptr, nullptr, nullptr, nullptr, (int)oriana_kpad(K), 1, 0, FU_next, mu_out, upart};
+        if (gu_vec_launch<false>(a, (hipStream_t)stream)) { ORIANA_LAUNCH_CHECK(); return 0; }
+    }
+    if (FU_next) return ORIANA_EINVAL;                 // (callers ask oriana_gamma_update_prep_blocks first)
     dim3 block;
     const bool big = gu_large_groups(r);
     pick_block(K, &block, big ? 512 : 256);          // (the general form needs more than the 128 VGPRs of a 1024-thread group)
@@ -271,15 +565,31 @@ extern "C" int oriana_gamma_update(double *a1, double *a2, double *E, float *Elo
     return 0;
 }
 
-extern "C" int oriana_gamma_update_finalize_from(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+extern "C" int oriana_gamma_update(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+                                   double *colsum_Elog, const double *prior1, const double *prior2, const float *Z,
+                                   const float *zmul, const double *rate_vec, const double *rate_mat,
+                                   const float *rmul, int64_t r, int64_t K, void *stream) {
+    return oriana_gamma_update_prep(a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, K,
+                                    nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int oriana_gamma_update_finalize_prep(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
                                             double *colsum_Elog, const double *prior1, const double *prior2, float *Z,
                                             const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
-                                            const double *rate_vec, int64_t r, int64_t K, void *stream) {
+                                            const double *rate_vec, int64_t r, int64_t K, float *FU_next, float *mu_out,
+                                            float *upart, void *stream) {
     if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535 || slab_row0 < 0) return ORIANA_EINVAL;
     const int64_t Kp = oriana_kpad(K);
     if (K > 128 * GU_MAXCOLS_PER_THREAD || Kp == 0) return ORIANA_EKRANGE;
     if (r == 0) return 0;
     if (!a1 || !a2 || !E || !Elog || !Z || !F || !R || !prior1 || !prior2 || !rate_vec) return ORIANA_EINVAL;
+    if (FU_next && (!mu_out || !upart)) return ORIANA_EINVAL;
+    if (!gu_scalar_forced()) {
+        GuVecArgs a = {a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, nullptr, nullptr, rate_vec, nullptr, nullptr, r, (int)K, 0,
+                       Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0, FU_next, mu_out, upart};
+        if (gu_vec_launch<true>(a, (hipStream_t)stream)) { ORIANA_LAUNCH_CHECK(); return 0; }
+    }
+    if (FU_next) return ORIANA_EINVAL;
     dim3 block;
     const bool big = gu_large_groups(r);
     pick_block(K, &block, big ? 1024 : 256);
@@ -295,6 +605,14 @@ extern "C" int oriana_gamma_update_finalize_from(double *a1, double *a2, double 
                            (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0);
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int oriana_gamma_update_finalize_from(double *a1, double *a2, double *E, float *Elog, double *colsum_E,
+                                            double *colsum_Elog, const double *prior1, const double *prior2, float *Z,
+                                            const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
+                                            const double *rate_vec, int64_t r, int64_t K, void *stream) {
+    return oriana_gamma_update_finalize_prep(a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, Z, F, R, nslab, slab_row0, row_index,
+                                             rate_vec, r, K, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int oriana_gamma_update_finalize(double *a1, double *a2, double *E, float *Elog, double *colsum_E,

@@ -525,6 +525,15 @@ class ZWorkspace:
         self.center_ptr = ptr(self.stats) + int(_lib.load().oriana_prep_center_offset())    # {sum, count} of E[log U] per factor (log sums)
         self.den_min_ptr = ptr(self.stats) + int(_lib.load().oriana_prep_den_threshold_offset())   # the row kernels' den threshold (float32, device)
         self.timer = None      # set to a KernelTimer to time the launches of a sweep
+        # [r5] the cell side of the NEXT sweep's factor preparation, written by the Gamma update that produces E[log U]
+        # (oriana_gamma_update_prep): FU in a second buffer (the gene-side kernels of the running sweep still read the
+        # current one), the row maxima, the per-group partial statistics.  fu_pending: they describe the E[log U] at hand.
+        self.prep_blocks = int(_lib.load().oriana_gamma_update_prep_blocks(max(ct.n, 0), int(K))) if ct.n > 0 else 0
+        if os.environ.get('ORIANA_FUSED_PREP', 'on') == 'off':          # A/B runs
+            self.prep_blocks = 0
+        self.FU_alt = self.mu_u = self.upart = None
+        self.fu_pending = False
+        self.fu_source = 0      # data pointer of the E[log U] matrix the pending preparation was made from
         self._extra = {}
         self._clear_cache = {}
         # gene-range split of the row pass (struct oriana_row_split: short matrices split every row block, long ones the row
@@ -583,6 +592,19 @@ class ZWorkspace:
         self.row_slab_row0 = int(nfull) * TILE
         f32 = dict(dtype=torch.float32, device=ct.device)
         self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32) if parts == 1 else torch.zeros(parts, ct.n, self.Kp, **f32)
+
+    def prep_outputs(self, packed_rows):
+        """(FU_next, mu, upart) for oriana_gamma_update[_finalize]_prep, or None when the cell side's Gamma update cannot
+        prepare the next sweep's factor: no vector kernel for this K, or -- `packed_rows` False: the update walks the
+        rows in the caller's order -- a count layout with a row permutation."""
+        if not self.prep_blocks or (not packed_rows and self.ct.row_perm is not None):
+            return None
+        if self.FU_alt is None:
+            f32 = dict(dtype=torch.float32, device=self.ct.device)
+            self.FU_alt = torch.zeros(max(self.ct.n, 1), self.Kp, **f32)
+            self.mu_u = torch.zeros(max(self.ct.n, 1), **f32)
+            self.upart = torch.zeros(4 * self.prep_blocks, **f32)
+        return self.FU_alt, self.mu_u, self.upart
 
     def extra(self, name, rows):
         """Lazily allocated padded (rows, Kp) scratch factor / accumulator matrices."""
@@ -691,11 +713,23 @@ def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None, clear=None):
     the two sides (oriana_factor_prep_pair): the sweeps drift along U c, V / c and only the sums matter.  `clear`: up to 8
     contiguous tensors zero-filled by the same launch (the outputs and scratch the passes accumulate into)."""
     ct = ws.ct
+    cl = None
     if clear:
         for t in clear:
             if t is not None and not t.is_contiguous():
                 raise ValueError('buffers on the clear list must be contiguous')
         cl = _clear_list(ws, clear)
+    if ws.fu_pending and ws.fu_source != log_U_hat.data_ptr():
+        ws.fu_pending = False               # (a caller's own E[log U]: the preparation at hand belongs to another matrix)
+    if ws.fu_pending:
+        # the cell side was prepared by the Gamma update that wrote this E[log U] (ZWorkspace.prep_outputs): the buffers swap,
+        # this launch combines the statistics, prepares the gene side and overwrites the rejected cell rows
+        ws.fu_pending = False
+        ws.FU, ws.FU_alt = ws.FU_alt, ws.FU
+        call('oriana_factor_prep_pair_fused', ptr(ws.FU), ptr(ws.mu_u), ptr(ws.upart), ws.prep_blocks, ptr(ws.FV), ptr(log_V_hat),
+             ptr(mask_v), ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), ctypes.byref(cl) if cl is not None else None, stream_ptr())
+        return
+    if cl is not None:
         call('oriana_factor_prep_pair_clear', ptr(ws.FU), ptr(ws.FV), ptr(log_U_hat), ptr(log_V_hat), ptr(mask_v),
              ptr(ct.row_perm), ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), ctypes.byref(cl), stream_ptr())
         return

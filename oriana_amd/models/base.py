@@ -75,6 +75,7 @@ class FactorModel:
 
     zi = False
     sparse = False
+    _graph_capturing = False
 
     def __init__(self, cmatrix, k=2, use_factors=True, tau=0.5, init=None, device=None, process_group=None,
                  reference_quirks=True, n_total=None, seed=0, dense_density='auto'):
@@ -258,6 +259,9 @@ class FactorModel:
             raise RuntimeError('graph capture is not available for the zero-inflated models (p_d is evaluated lazily on the host side)')
         if self._graph is not None:
             return self
+        # (a captured sweep replays fixed buffers: the FU double buffer of the fused preparation would alternate)
+        self._graph_capturing = True
+        self._ws.fu_pending = False
         self._sweep()                          # warm-up: allocations, lazy scratch buffers
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -314,9 +318,22 @@ class FactorModel:
             sums = sums_arg
         if zero:
             sums.zero_()
-        call('oriana_gamma_update', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
+        prep = self._prep_outputs(side, packed_rows=False)
+        call('oriana_gamma_update_prep', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
              ptr(p1.tensor), ptr(p2.tensor), ptr(Z) if update else None, ptr(zmul), ptr(rate_vec), ptr(rate_mat),
-             ptr(rmul), r, self.k, stream_ptr())
+             ptr(rmul), r, self.k, ptr(prep[0]), ptr(prep[1]), ptr(prep[2]), stream_ptr())
+        if prep[0] is not None:
+            self._ws.fu_pending, self._ws.fu_source = True, Elog.data_ptr()
+
+    def _prep_outputs(self, side, packed_rows):
+        """The cell-side update also prepares the next sweep's FU (engine.ZWorkspace.prep_outputs); any update of E[log U]
+        invalidates what an earlier one prepared."""
+        if side != 'u' or getattr(self, '_ws', None) is None:
+            return (None, None, None)
+        self._ws.fu_pending = False
+        if self._graph_capturing:
+            return (None, None, None)
+        return self._ws.prep_outputs(packed_rows) or (None, None, None)
 
     def _gamma_side_finalize(self, side, Z, F, R, row_index, rate_vec, sums, nslab=1, slab_row0=0):
         """pCMF: Z += F * R (the last step of the responsibility pass, packed rows scattered through `row_index`) and the
@@ -327,9 +344,12 @@ class FactorModel:
             s1, s2, E, Elog, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self.alpha1, self.alpha2, self.n
         else:
             s1, s2, E, Elog, p1, p2, r = self.b1, self.b2, self._V_hat, self._log_V_hat, self.beta1, self.beta2, self.m
-        call('oriana_gamma_update_finalize_from', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
+        prep = self._prep_outputs(side, packed_rows=True)
+        call('oriana_gamma_update_finalize_prep', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
              ptr(p1.tensor), ptr(p2.tensor), ptr(Z), ptr(F), ptr(R), int(nslab), int(slab_row0), ptr(row_index), ptr(rate_vec), r,
-             self.k, stream_ptr())
+             self.k, ptr(prep[0]), ptr(prep[1]), ptr(prep[2]), stream_ptr())
+        if prep[0] is not None:
+            self._ws.fu_pending, self._ws.fu_source = True, Elog.data_ptr()
 
     def _mstep_side(self, side):
         if side == 'u':
@@ -521,6 +541,7 @@ class FactorModel:
             if k in st:
                 t.copy_(torch.as_tensor(np.asarray(st[k])).to(self.device, dtype=t.dtype))
         self._touch()
+        self._ws.fu_pending = False             # (E[log U] was overwritten)
         # column sums that the next sweep reads
         self._sumU[0] = self._U_hat.sum(0); self._sumU[1] = self._log_U_hat.double().sum(0)
         odist.all_reduce_sum(self._sumU, self.pg)

@@ -31,6 +31,16 @@ def main():
         st = stream_ptr()
         t = timed(lambda: call('oriana_gamma_update_finalize', ptr(a1), ptr(a2), ptr(E), ptr(El), ptr(sums[0]), ptr(sums[1]),
                                ptr(p1), ptr(p2), ptr(Z), ptr(F), ptr(R), 1, ptr(idx), ptr(rate), r, K, st))
+        nblk = int(__import__('oriana_amd')._lib.load().oriana_gamma_update_prep_blocks(r, K))
+        tp = float('nan')
+        if nblk:
+            FUn = torch.zeros(r, Kp, device=dev); mu = torch.zeros(r, device=dev); up = torch.zeros(4 * nblk, device=dev)
+            tp = timed(lambda: call('oriana_gamma_update_finalize_prep', ptr(a1), ptr(a2), ptr(E), ptr(El), ptr(sums[0]), ptr(sums[1]),
+                                    ptr(p1), ptr(p2), ptr(Z), ptr(F), ptr(R), 1, 0, None, ptr(rate), r, K, ptr(FUn), ptr(mu), ptr(up), st))
+            tn = timed(lambda: call('oriana_gamma_update_finalize_prep', ptr(a1), ptr(a2), ptr(E), ptr(El), ptr(sums[0]), ptr(sums[1]),
+                                    ptr(p1), ptr(p2), ptr(Z), ptr(F), ptr(R), 1, 0, None, ptr(rate), r, K, None, None, None, st))
+            print('   no row permutation: %.1f us (%.2f TB/s at 44 B); with the next sweep\'s FU, row maxima, statistics: %.1f us (%.2f TB/s at 48 B)' % (
+                tn, 44.0 * r * K / (tn * 1e-6) / 1e12, tp, 48.0 * r * K / (tp * 1e-6) / 1e12))
         q = [p1.clone(), p2.clone(), p1.clone(), p2.clone()]
         keep = torch.zeros(2, K, dtype=torch.float64, device=dev)
         sE = torch.rand(K, dtype=torch.float64, device=dev) * r + r

@@ -253,7 +253,12 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
                 st_f64<VEC>(A.a1 + idx, s1);
                 st_f64<VEC>(A.a2 + idx, s2);
                 #pragma unroll
-                for (int v = 0; v < VEC; ++v) el[v] = gamma_meanlog_f32_lg(s1[v], lg2c[v]);
+                for (int v = 0; v < VEC; ++v)
+#ifdef ORIANA_GU_ABL_NOSPECIAL                                      /* analysis build: the memory side of the kernel alone */
+                    el[v] = (float)s1[v] - lg2c[v];
+#else
+                    el[v] = gamma_meanlog_f32_lg(s1[v], lg2c[v]);
+#endif
             } else if (A.Z_in) {
                 float z[VEC];
                 ld_f32<VEC>(z, A.Z_in + idx);
@@ -289,7 +294,11 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
             }
             #pragma unroll
             for (int v = 0; v < VEC; ++v) {
+#ifdef ORIANA_GU_ABL_NOSPECIAL
+                e[v] = s1[v] * s2[v];
+#else
                 e[v] = s1[v] / s2[v];                                                       // gamma.py:37-46
+#endif
                 sE[v] += e[v];
                 sL[v] += (double)el[v];
             }
@@ -308,7 +317,12 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
             if (in) {
                 float fu[VEC];
                 #pragma unroll
-                for (int v = 0; v < VEC; ++v) fu[v] = (float)exp((double)el[v] - (double)mx);
+                for (int v = 0; v < VEC; ++v)
+#if defined(ORIANA_GU_ABL_NOSPECIAL) || defined(ORIANA_GU_ABL_NOEXP)
+                    fu[v] = el[v] - mx;
+#else
+                    fu[v] = (float)exp((double)el[v] - (double)mx);
+#endif
                 st_f32<VEC>(A.FUn + row * Kp + k0, fu);
                 if (cg == 0) {
                     A.mu_out[row] = badi ? NAN : mx;

@@ -180,6 +180,57 @@ def main():
                 print('wrote', fn, 'zeros=%.3f' % (out['X'] == 0).mean())
 
 
+def xcheck_case(oriana, g):
+    """SURVEY 8(a) policy (ii): the patched SparseGaP fixture cross-checked by the reference's UNPATCHED SparseZIGaP class
+    with D_hat == 1 (sparse_zigap.py:114-116, 140, 147-148, 155 then reduce to sparse_gap.py:95-97, 119-120, 127-128, 136).
+    For each single sweep s_a -> s_b of a sparsegap golden `g`: a SparseZIGaP model on the same X gets the golden's state
+    s_a (parameters and expectations), D_hat = 1 (float32), runs its own step(), and the keys the two models share are
+    recorded as xcheck/s_b/<key>.  Data only: the golden's inputs and the reference's outputs."""
+    from oriana.singlecell import CountMatrix
+    X = np.asarray(g['X'])
+    k = int(g['meta/k'])
+    out = {'X': X, 'meta/k': np.array(k), 'meta/tau': np.array(float(g['meta/tau'])),
+           'meta/what': np.array('reference SparseZIGaP.step() with D_hat == 1 from the sparsegap golden states')}
+    np.random.seed(12345)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = oriana.models.SparseZIGaP(CountMatrix(X), k=k, use_factors=False, tau=float(g['meta/tau']))
+        for a, b in (('s0', 's1'), ('s1', 's2'), ('s2', 's3')):
+            for key in ('alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_s', 'p_s'):
+                getattr(model, key)[:] = g['%s/%s' % (a, key)]
+            model.U_hat = np.array(g[a + '/U_hat']); model.log_U_hat = np.array(g[a + '/log_U_hat'])
+            model.Vprime_hat = np.array(g[a + '/V_hat']); model.log_Vprime_hat = np.array(g[a + '/log_V_hat'])
+            model.S_hat = np.array(g[a + '/S_hat'])
+            model.D_hat = np.ones(X.shape, dtype=np.float32)
+            model.pi_d[:] = 1.0
+            model.step()
+            tmp = {}
+            snapshot(model, b, tmp)
+            for kk, v in tmp.items():
+                if kk.split('/')[1] not in ('p_d', 'pi_d'):
+                    out['xcheck/' + kk] = v
+    return out
+
+
+def main_xcheck():
+    oriana = import_reference()
+    import glob
+    for path in sorted(glob.glob(os.path.join(HERE, 'sparsegap_*_*.npz'))):
+        if path.endswith('_xcheck.npz'):
+            continue
+        g = dict(np.load(path))
+        out = xcheck_case(oriana, g)
+        worst = 0.0
+        for kk, v in out.items():
+            if kk.startswith('xcheck/'):
+                ref = np.asarray(g[kk[len('xcheck/'):]], dtype=np.float64)
+                d = np.abs(np.asarray(v, dtype=np.float64) - ref) / (np.abs(ref) + np.abs(ref).max(axis=0, keepdims=True) + 1e-300)
+                worst = max(worst, float(np.nanmax(d)))
+        fn = os.path.basename(path)[:-4] + '_xcheck.npz'
+        np.savez_compressed(os.path.join(HERE, fn), **out)
+        print('wrote', fn, 'largest column-relative difference from the patched-SparseGaP golden: %.3e' % worst)
+
+
 def main_metrics():
     oriana = import_reference()
     for tag, (n, m, k, seed) in {'c1': (200, 80, 5, 0), 'odd': (257, 131, 7, 100)}.items():
@@ -243,9 +294,12 @@ def main_generator():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'metrics':
         main_metrics()          # only the metrics fixtures (the sweep fixtures are left as they are)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'xcheck':
+        main_xcheck()           # the patched SparseGaP fixtures cross-checked by the unpatched SparseZIGaP class (D_hat == 1)
     elif len(sys.argv) > 1 and sys.argv[1] == 'generator':
         main_generator()        # moments of the reference's synthetic-data generator
     else:
         main()
         main_metrics()
         main_generator()
+        main_xcheck()

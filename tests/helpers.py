@@ -31,7 +31,14 @@ def golden_files(pattern='*_*.npz'):
     skip_metrics = not pattern.startswith('metrics_')
     return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern))
                   if not f.endswith('tables.npz') and not os.path.basename(f).startswith('generator_')
+                  and not f.endswith('_xcheck.npz')
                   and not (skip_metrics and os.path.basename(f).startswith('metrics_')))
+
+
+def xcheck_files():
+    """The patched-SparseGaP fixtures cross-checked by the reference's unpatched SparseZIGaP class with D_hat == 1
+    (tests/golden/make_golden.py xcheck; SURVEY 8a policy ii)."""
+    return sorted(glob.glob(os.path.join(GOLDEN, 'sparsegap_*_xcheck.npz')))
 
 
 def load_golden(path):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden_files, load_golden, state_of, assert_state_close, exact_twin, err_colrel
+from helpers import golden_files, load_golden, state_of, assert_state_close, exact_twin, err_colrel, xcheck_files
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,37 @@ def test_single_sweeps(path):
             E.step()
             exact = E.state()
         assert_state_close(M.state(), state_of(g, b), what='%s->%s' % (a, b), exact=exact)
+
+
+@pytest.mark.parametrize('path', xcheck_files(), ids=os.path.basename)
+def test_sparsezigap_with_unit_dropout_reproduces_the_sparsegap_goldens(path):
+    """SURVEY 8(a) policy (ii) on the HIP path: SparseZIGaP with D_hat == 1, pi_d == 1 is algebraically SparseGaP
+    (sparse_zigap.py:114-116, 140, 147-148, 155 with D = 1), so its single sweeps from the sparsegap goldens' states must land
+    on the sparsegap goldens' next states -- which tests/test_oracle.py shows to be, bit for bit, what the reference's own
+    unpatched SparseZIGaP class produces.  Runs the weighted nest, D_hat V, D_hat^T U on the matrix cores, the S update with
+    the matrix rate -- none of which the SparseGaP model touches."""
+    from oracle import cavi_oracle as co
+    import oriana_amd.models as models
+    g = load_golden(path.replace('_xcheck.npz', '.npz'))
+    n, m = g['X'].shape
+    M = models.SparseZIGaP(g['X'], k=int(g['meta/k']), use_factors=False, tau=float(g['meta/tau']), init=(g['s0/a1'], g['s0/b1']))
+    shared = ['alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_s', 'p_s', 'U_hat', 'V_hat', 'log_U_hat',
+              'log_V_hat', 'S_hat']
+    for a, b in (('s0', 's1'), ('s1', 's2'), ('s2', 's3')):
+        st = dict(state_of(g, a))
+        st['p_d'] = np.ones((n, m))
+        st['pi_d'] = np.ones(m)
+        M.load_state(st)
+        assert float(M._D_hat.min()) == 1.0
+        M.step()
+        exact = None
+        if not bool(g['meta/use_factors']):
+            E = co.MODELS['SparseGaP'](g['X'], int(g['meta/k']), g['s0/a1'], g['s0/b1'], tau=float(g['meta/tau']))
+            E.load_state(state_of(g, a))
+            E.exact = True
+            E.step()
+            exact = E.state()
+        assert_state_close(M.state(), state_of(g, b), keys=shared, what='SparseZIGaP(D = 1) %s->%s' % (a, b), exact=exact)
 
 
 @pytest.mark.parametrize('path', golden_files('gap_*.npz') + golden_files('zigap_*.npz') + golden_files('sparsegap_*.npz')

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import golden_files, load_golden, state_of, assert_state_close, err_colrel
+from helpers import golden_files, load_golden, state_of, assert_state_close, err_colrel, xcheck_files
 from oracle import cavi_oracle as co
 
 
@@ -63,6 +63,33 @@ def test_trajectory(path):
     for _ in range(10):
         M.step()
     assert_state_close(M.state(), state_of(g, 's10'), rtol=2e-3, what='s10')
+
+
+@pytest.mark.parametrize('path', xcheck_files(), ids=os.path.basename)
+def test_patched_sparsegap_fixture_cross_checked_by_sparsezigap(path):
+    """SURVEY 8(a) policy (ii).  SparseGaP.step() cannot run in the reference (sparse_gap.py:127 reads a bare `S_hat`); its
+    goldens were captured with that one name bound (make_golden.py).  Independent check: the reference's UNPATCHED
+    SparseZIGaP class with D_hat == 1 is algebraically the same sweep (sparse_zigap.py:114-116, 140, 147-148, 155 reduce to
+    sparse_gap.py:95-97, 119-120, 127-128, 136).  (1) Its states, recorded from the reference by `make_golden.py xcheck`,
+    ARE the patched fixture's states -- bit for bit.  (2) The oracle's SparseZIGaP restatement with D_hat == 1 lands on them
+    too (its D update is the only statement that differs, and nothing of this sweep reads its result)."""
+    x = load_golden(path)
+    g = load_golden(path.replace('_xcheck.npz', '.npz'))
+    n_keys = 0
+    for k, v in x.items():
+        if k.startswith('xcheck/'):
+            assert np.array_equal(v, g[k[len('xcheck/'):]]), k
+            n_keys += 1
+    assert n_keys == 3 * 15
+    shared = ['alpha1', 'alpha2', 'beta1', 'beta2', 'a1', 'a2', 'b1', 'b2', 'pi_s', 'p_s', 'U_hat', 'V_hat', 'log_U_hat',
+              'log_V_hat', 'S_hat']
+    for a, b in (('s0', 's1'), ('s1', 's2'), ('s2', 's3')):
+        M = co.MODELS['SparseZIGaP'](g['X'], int(g['meta/k']), g['s0/a1'], g['s0/b1'], tau=float(g['meta/tau']))
+        M.load_state(state_of(g, a))
+        M.D_hat = np.ones(g['X'].shape, dtype=np.float32)
+        M.pi_d = np.ones(g['X'].shape[1])
+        M.step()
+        assert_state_close(M.state(), state_of(g, b), keys=shared, what='SparseZIGaP(D = 1) %s->%s' % (a, b))
 
 
 def test_tables(golden_dir):

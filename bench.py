@@ -43,10 +43,15 @@ WORKLOADS = {
     'c2': ('GaP', 10000, 2000, 20, 0.10, 'configs[1]'),
     'c3_zi': ('ZIGaP', 100000, 20000, 50, 0.10, 'configs[2]'),
     'c5_sparse': ('SparseGaP', 500000, 25000, 64, 0.10, 'configs[4]'),
+    'c4_half': ('GaP', 500000, 30000, 100, 0.10, 'one rank\'s share of configs[3] at 2 GPUs'),
+    'c4_quarter': ('GaP', 250000, 30000, 100, 0.10, 'one rank\'s share of configs[3] at 4 GPUs'),
     'c4_eighth': ('GaP', 125000, 30000, 100, 0.10, 'one rank\'s share of configs[3] at 8 GPUs'),
     'c4_eighth_z05': ('GaP', 125000, 30000, 100, 0.50, 'the same share at the reference generator\'s default z'),
     'c3_zi_z05': ('ZIGaP', 100000, 20000, 50, 0.50, 'configs[2] at the reference generator\'s default z'),
     'c5_sparse_z05': ('SparseGaP', 500000, 25000, 64, 0.50, 'configs[4] at the reference generator\'s default z'),
+    # [r5] configs[2] from the reference's DEFAULT start (use_factors=True, oriana/models/base.py:15, 37-40): NMF factors as
+    # initial shapes (computed on the device); the first sweeps pass through a transient with many slow-path tiles
+    'c3_zi_nmf': ('ZIGaP', 100000, 20000, 50, 0.10, 'configs[2] from the reference\'s default NMF start'),
 }
 MODEL_LABEL = {'GaP': 'pCMF', 'ZIGaP': 'ZI-pCMF', 'SparseGaP': 'sparse pCMF'}
 
@@ -60,6 +65,7 @@ def parse():
     ap.add_argument('--cpu-rows', type=int, default=int(os.environ.get('ORIANA_BENCH_CPU_ROWS', '0')),
                     help='rows of the CPU baseline sample (0: sized for ~15 s of single-thread work)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--brief', action='store_true', help='a secondary workload of the headline line: short keys, small CPU sample')
     ap.add_argument('--chunk-rows', type=int, default=8192)
     ap.add_argument('--dense-density', default=os.environ.get('ORIANA_DENSE_DENSITY', 'auto'),
                     help="pCMF: genes expressed in at least this share of the cells are evaluated on the bf16 matrix cores "
@@ -77,10 +83,17 @@ def self_launch(args):
     s.close()
     import tempfile
     procs, errs = [], []
+    # every rank's stderr goes to a NAMED file (gpurun_out/bench_ranks/rank<r>.err, or the temporary directory): if this
+    # process is killed -- the driver's limit -- the ranks' diagnostics and RCCL errors survive it; replayed below otherwise
+    logdir = os.path.join(ROOT, 'gpurun_out', 'bench_ranks')
+    try:
+        os.makedirs(logdir, exist_ok=True)
+    except OSError:
+        logdir = tempfile.mkdtemp(prefix='bench_ranks_')
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        ef = tempfile.TemporaryFile(mode='w+')          # the rank's stderr: replayed below, summarised on failure
+        ef = open(os.path.join(logdir, 'rank%d.err' % r), 'w+')
         errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=ef))
     # poll: the first rank to fail takes its siblings down (they would otherwise block in their next collective until
@@ -165,7 +178,12 @@ def main():
     force_pg = world == 1 and os.environ.get('ORIANA_BENCH_FORCE_PG') == '1'
     if force_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
+        if 'MASTER_PORT' not in os.environ:                     # (a free port: two rehearsals may share a box)
+            import socket
+            sk = socket.socket()
+            sk.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+            sk.close()
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ['ORIANA_FORCE_SHARDED'] = '1'
@@ -181,27 +199,61 @@ def main():
         sys.stdout.flush()
         os.dup2(2, 1)
     out = measure(args, args.workload, args.steps, args.warmup, world, rank, dev, np, torch, dist,
-                  cpu_rows=(None if args.no_cpu else args.cpu_rows))
+                  cpu_rows=(None if args.no_cpu else args.cpu_rows), brief=args.brief)
     if world > 1 or force_pg:
         dist.barrier()
         dist.destroy_process_group()
     _flush_c_stdio()                 # (rank 0: the banner leaves the buffer BEFORE the line, not at exit after it)
     if rank == 0:
         # The other single-GPU configurations of BASELINE.json ride in the SAME json line (so that the driver's run, not
-        # only profiles/, carries them): configs[2] (ZI-pCMF) and configs[4] (sparse pCMF), a short run each after the
-        # headline measurement, with their own roofline objects and parity slabs.  ORIANA_BENCH_SECONDARY=0 skips them.
-        if (world == 1 and args.workload == 'c4' and not args.no_cpu
+        # only profiles/, carries them): configs[2] (ZI-pCMF; also from the reference's default NMF start) and configs[4]
+        # (sparse pCMF), a short run each after the headline measurement, with their own roofline objects and parity slabs.
+        # [r5] Each runs in a FRESH CHILD PROCESS under a wall-clock budget: a fault, an abort or a hang there cannot cost
+        # the headline, which is also written to gpurun_out/bench_headline.json before they start.  ORIANA_BENCH_SECONDARY=0
+        # skips them; ORIANA_BENCH_SECONDARY_BUDGET_S (default 420) bounds their total time.
+        if (world == 1 and args.workload == 'c4' and not args.no_cpu and not args.brief
                 and os.environ.get('ORIANA_BENCH_SECONDARY', '1') != '0'):
-            out['secondary_workloads'] = []
-            for wl in ('c3_zi', 'c5_sparse'):
-                try:
-                    sub = measure(args, wl, 10, 3, world, rank, dev, np, torch, dist, cpu_rows=400, brief=True)
-                except Exception as exc:            # never let an extra figure break the bench line
-                    sub = {'workload': wl, 'error': repr(exc)[:300]}
-                out['secondary_workloads'].append(sub)
+            try:
+                os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                with open(os.path.join(ROOT, 'gpurun_out', 'bench_headline.json'), 'w') as f:
+                    f.write(json.dumps(out) + '\n')
+            except OSError:
+                pass
+            out['secondary_workloads'] = run_secondaries(('c3_zi', 'c5_sparse', 'c3_zi_nmf'))
         _flush_c_stdio()
         print(json.dumps(out))
         sys.stdout.flush()
+
+
+def run_secondaries(names):
+    """Each secondary workload as `python bench.py --workload <name> --brief` in a child process (this process has finished
+    its GPU work and freed its memory), under what is left of a total budget; a failure becomes an {'error': ...} entry."""
+    budget = float(os.environ.get('ORIANA_BENCH_SECONDARY_BUDGET_S', '420'))
+    t_end = time.time() + budget
+    res = []
+    for wl in names:
+        left = t_end - time.time()
+        if left < 45:
+            res.append({'workload': wl, 'error': 'skipped: %.0f s left of the secondary budget' % max(left, 0.0)})
+            continue
+        env = dict(os.environ, ORIANA_BENCH_SECONDARY='0')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'ORIANA_BENCH_FORCE_PG', 'ORIANA_FORCE_SHARDED'):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', '26' if wl.endswith('_nmf') else '10',
+               '--warmup', '0' if wl.endswith('_nmf') else '3', '--cpu-rows', '400', '--brief']
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left)
+            lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+            if p.returncode == 0 and lines:
+                res.append(json.loads(lines[-1]))
+            else:
+                tail = [l for l in p.stderr.splitlines() if l.strip()]
+                res.append({'workload': wl, 'error': 'rc=%d: %s' % (p.returncode, (tail[-1] if tail else '')[:300])})
+        except subprocess.TimeoutExpired:
+            res.append({'workload': wl, 'error': 'timed out after %.0f s (child stopped)' % left})
+        except Exception as exc:                # never let an extra figure break the bench line
+            res.append({'workload': wl, 'error': repr(exc)[:300]})
+    return res
 
 
 def _flush_c_stdio():
@@ -230,6 +282,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     r0, r1 = odist.shard_rows(n_total, rank, world)
     n = r1 - r0
     seed = 1234 + 1000 * 4
+    torch.cuda.reset_peak_memory_stats()          # (hbm_gb_rank0 of THIS workload, not the process-wide peak)
     t_setup = time.time()
     gen = SyntheticCounts(n_total, m, K, seed=seed, device=dev, zero_inflation_level=z, row0=r0, n=n)
     dd = None
@@ -245,10 +298,17 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     counts = engine.CountTiles.from_chunks(n, m, gen.chunk, args.chunk_rows, dev,
                                            reduce_fn=(lambda t: odist.all_reduce_sum(t)) if (world > 1 or odist.sharded()) else None,
                                            dense_density=dd, n_total=n_total, dense_min_share=min_share)
-    a1, b1 = gen.initial_shapes()
-    model = getattr(models, mname)(counts, k=K, use_factors=False, init=(a1, b1), device=dev,
-                                   process_group=(dist.group.WORLD if (world > 1 or odist.sharded()) else None), n_total=n_total)
-    del a1, b1
+    nmf_start = args.workload.endswith('_nmf')
+    if nmf_start:
+        # the reference's DEFAULT start (use_factors=True, base.py:15, 37-40): NMF factors as initial shapes, here computed on
+        # the device from the packed counts (models/deviceinit.py; the reference calls scikit-learn on the dense host matrix)
+        model = getattr(models, mname)(counts, k=K, use_factors=True, init='nmf', device=dev, seed=seed,
+                                       process_group=(dist.group.WORLD if (world > 1 or odist.sharded()) else None), n_total=n_total)
+    else:
+        a1, b1 = gen.initial_shapes()
+        model = getattr(models, mname)(counts, k=K, use_factors=False, init=(a1, b1), device=dev,
+                                       process_group=(dist.group.WORLD if (world > 1 or odist.sharded()) else None), n_total=n_total)
+        del a1, b1
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -268,6 +328,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     marks = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sampled}
     if world > 1 or odist.sharded():
         model._xch.timing = True         # events around every blocking exchange: allreduce_exposed_ms
+    flagged = []                     # (NMF-start workload: slow-path tiles of every sweep -- one host read per sweep)
+    ntiles = counts.nrb * counts.ncb
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -279,6 +341,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
             model._ws.timer = None
         else:
             model.step()
+        if nmf_start:
+            flagged.append(int(model._ws.tile_flag[:max(ntiles, 1)].sum().item()))
     barrier()
     elapsed = time.perf_counter() - t0
     model._ws.timer = None
@@ -292,7 +356,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     # collectives of one sweep's exchange (counted over the sweeps run so far: warm-up + timed)
     coll_per_sweep = round(model._xch.n_collectives / max(model._xch.n_reduces, 1))
     value = args.steps / elapsed
-    step_ms = sorted(a.elapsed_time(b) for a, b in marks.values())
+    sweep_ms = [marks[i][0].elapsed_time(marks[i][1]) for i in sorted(marks)]
+    step_ms = sorted(sweep_ms)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     ks = {k: v[1] * v[0] / len(sampled) for k, v in timer.summary().items()}       # ms per sweep and kernel group
@@ -451,6 +516,13 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                                'before the dense gene-side kernel, the dense genes\' segment after it')
         if stateless is not None:
             out['stateless_binding'] = stateless
+        if nmf_start:
+            settled = sorted(sweep_ms[-5:])[len(sweep_ms[-5:]) // 2]
+            out['transient'] = {'what': 'sweeps 0..%d after the reference\'s default start (use_factors=True: NMF factors as initial '
+                                        'shapes, base.py:37-40): ms of every sweep (HIP events), tiles with slow-path entries' % (args.steps - 1),
+                                'sweep_ms': [round(v, 3) for v in sweep_ms], 'mean_ms': sum(sweep_ms) / len(sweep_ms),
+                                'max_ms': max(sweep_ms), 'max_ms_from_sweep_1': max(sweep_ms[1:]) if len(sweep_ms) > 1 else None,
+                                'settled_ms': settled, 'flagged_tiles': flagged, 'tiles': int(ntiles)}
         if world == 1 and odist.sharded():
             out['exchange_rehearsal'] = {'backend': dist.get_backend(), 'ranks': 1, 'exchanges': int(model._xch.n_reduces),
                                          'exposed_ms': exposed_ms,
@@ -458,7 +530,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                                          'what': 'one-rank process group: every collective of the sharded sweep issued as a self all-reduce'}
         if brief:
             keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'dtype', 'config',
-                    'roofline', 'parity_slab', 'f64_reference_arithmetic_ms', 'cpu_baseline', 'check')
+                    'roofline', 'parity_slab', 'f64_reference_arithmetic_ms', 'cpu_baseline', 'check', 'transient')
             out = {k: out[k] for k in keep if k in out}
             out['workload'] = workload
     else:
@@ -496,27 +568,60 @@ def recorded_traffic(workload, world, hybrid=False):
 
 
 def stateless_binding_ms(np, torch, engine, model, gen, m, K, dev, rows=2048):
-    """The drop-in kernel boundary as INTEGRATION.md section B binds it (oriana_zq_gap_f32: dense float32 device
-    matrices in the reference's argument order, no resident state): every call packs X into the sliced layout, runs the
-    pass and synchronises.  Timed once here so that the figure exists: ms per call on the first `rows` cells."""
+    """The drop-in kernel boundary as INTEGRATION.md section B binds it.  (1) oriana_zq_gap_f32: dense float32 device
+    matrices in the reference's argument order, no resident state -- every call packs X into the sliced layout, runs the
+    pass and synchronises.  (2) [r5] the RESIDENT handle: oriana_counts_create_dense_f32 once (pack + plans in C host code, the
+    layout of the run: hybrid when the model's is), then oriana_zq_gap_resident per call.  (3) the same slab through the
+    Python host path the models use (engine.CountTiles + engine.zq_gap), timed the same way.  ms per call on the first
+    `rows` cells."""
+    import ctypes
     rows = min(rows, gen.n)
     X = gen.chunk(0, rows).to(torch.float32).contiguous()
     lu = model._log_U_hat[:rows].contiguous()
     lv = model._log_V_hat.contiguous()
     Zi = torch.empty(rows, K, device=dev); Zj = torch.empty(m, K, device=dev)
-    for _ in range(2):
-        engine.zq_gap_stateless(Zi, Zj, lu, lv, X)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        engine.zq_gap_stateless(Zi, Zj, lu, lv, X)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    return {'entry': 'oriana_zq_gap_f32 (csrc/stateless.hip)', 'rows': rows, 'genes': m, 'K': K, 'ms_per_call': ms,
-            'dense_x_gb_per_s': 4.0 * rows * m / (ms * 1e-3) / 1e9,
-            'note': 'packs the dense X on every call (sliced layout only, no matrix-core path) and synchronises; the resident '
-                    'model path amortises the packing over the sweeps'}
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    ms = timed(lambda: engine.zq_gap_stateless(Zi, Zj, lu, lv, X), 5)
+    out = {'entry': 'oriana_zq_gap_f32 (csrc/stateless.hip)', 'rows': rows, 'genes': m, 'K': K, 'ms_per_call': ms,
+           'dense_x_gb_per_s': 4.0 * rows * m / (ms * 1e-3) / 1e9,
+           'note': 'packs the dense X on every call (sliced layout only, no matrix-core path) and synchronises; the resident '
+                   'handle / the resident model path amortise the packing over the sweeps'}
+    try:
+        lib = engine._lib.load()
+        dd = float(getattr(model.counts, 'dense_density', None) or 0.0)
+        h = ctypes.c_void_p(None)
+        t0 = time.perf_counter()
+        engine.call('oriana_counts_create_dense_f32', ctypes.addressof(h), engine.ptr(X), rows, m, m, K, dd, engine.stream_ptr())
+        torch.cuda.synchronize()
+        create_ms = (time.perf_counter() - t0) * 1e3
+        st = engine.stream_ptr()
+        res_ms = timed(lambda: engine.call('oriana_zq_gap_resident', h, engine.ptr(Zi), engine.ptr(Zj), engine.ptr(lu), engine.ptr(lv), st), 20)
+        Zi_r, Zj_r = Zi.clone(), Zj.clone()
+        info = (ctypes.c_int64 * 13)()
+        lib.oriana_counts_info(h, info, 13)
+        lib.oriana_counts_destroy(h)
+        ct = engine.CountTiles.from_dense(X, dev, dense_density=dd or None)
+        ws = engine.ZWorkspace(ct, K)
+        py_ms = timed(lambda: engine.zq_gap(ws, Zi, Zj, lu, lv), 20)
+        torch.cuda.synchronize()
+        scale = float(Zj.abs().max().item()) or 1.0
+        out.update({'resident_entry': 'oriana_counts_create_dense_f32 + oriana_zq_gap_resident (csrc/resident.hip)',
+                    'resident_create_ms': create_ms, 'resident_ms_per_call': res_ms, 'model_path_ms_per_call': py_ms,
+                    'resident_vs_model_path': res_ms / py_ms if py_ms > 0 else None,
+                    'resident_dense_genes': int(info[5]), 'resident_bytes': int(info[8]),
+                    'resident_vs_model_path_max_abs_diff_rel': float(max((Zi_r - Zi).abs().max().item(), (Zj_r - Zj).abs().max().item()) / scale)})
+    except Exception as exc:                        # never let the extra figure break the bench line
+        out['resident_error'] = repr(exc)[:300]
+    return out
 
 
 def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, rows, dev, openmp=True):
@@ -658,15 +763,27 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
         def colrel(got, ref):
             cm = np.abs(ref).max(axis=0, keepdims=True)
             return float((np.abs(got.astype(np.float64) - ref) / (np.abs(ref) + cm + 1e-300)).max())
+        def strictrel(got, ref):
+            # strictly element-wise |d| / |ref| over the entries that are not negligible in their column (|ref| >= 1e-6 of
+            # the column's largest: below that an entry is rounding noise of the sums it belongs to)
+            cm = np.abs(ref).max(axis=0, keepdims=True)
+            big = np.abs(ref) >= 1e-6 * cm + 1e-300
+            if not big.any():
+                return 0.0
+            return float((np.abs(got.astype(np.float64) - ref)[big] / np.abs(ref)[big]).max())
         slab = {'rows': srows, 'what': 'the workload\'s loop nest (%s) on the first rows, from the model\'s current E[log U], E[log V]: '
-                                       'HIP vs oracle, max |d| / (|ref| + colmax|ref|)' % nest,
+                                       'HIP vs oracle, max |d| / (|ref| + colmax|ref|); *_strict: max |d| / |ref| element-wise over the '
+                                       'entries with |ref| >= 1e-6 of their column\'s largest' % nest,
                 'Z_i': colrel(Zi_h.cpu().numpy(), Zi_o.astype(np.float64)),
                 'Z_j': colrel(Zj_h.cpu().numpy(), Zj_o.astype(np.float64)),
+                'Z_i_strict': strictrel(Zi_h.cpu().numpy(), Zi_o.astype(np.float64)),
+                'Z_j_strict': strictrel(Zj_h.cpu().numpy(), Zj_o.astype(np.float64)),
                 'dense_genes': int(ct.gd)}
         if mname == 'GaP':
             slab['conservation'] = float(abs(float(Zi_h.double().sum().item()) - float(Xs.astype(np.float64).sum())) / max(float(Xs.sum()), 1.0))
         if Zl_h is not None:
             slab['Z_log'] = colrel(Zl_h.cpu().numpy(), Zl_o.astype(np.float64))
+            slab['Z_log_strict'] = strictrel(Zl_h.cpu().numpy(), Zl_o.astype(np.float64))
         slab.update(extra)
     except Exception as e:
         import traceback

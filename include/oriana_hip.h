@@ -215,6 +215,13 @@ typedef struct oriana_row_split {
  * short-matrix rule. */
 int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const double *tile_cost, oriana_row_split *out);
 
+/* [r5] The same for a given number of compute units (oriana_row_pass_plan uses oriana_device_cus()): host code only, no
+ * device call -- the plan of a 128-, 256- or 304-CU part can be formed (and tested) anywhere. */
+int oriana_row_pass_plan_cus(const oriana_counts *cm, int64_t K, const double *tile_cost, int64_t cus, oriana_row_split *out);
+/* Compute units of the device the calling thread has selected (hipDeviceAttributeMultiprocessorCount, cached per device;
+ * the environment's ORIANA_CUS overrides; 256 where no device is visible): the "rounds of the chip" every plan counts in. */
+int64_t oriana_device_cus(void);
+
 /* [r4] Every variant of the row pass behind one entry: oriana_row_pass (FV2 = NULL) or oriana_row_pass_masked (FV2 given,
  * s_rs must be NULL; ORIANA_EKRANGE where the two images do not fit) under a split (NULL = none); s_rs given: R untouched.
  * Kernels other than the two-lane ones take nfull = 0 only (ORIANA_EINVAL otherwise) and cut their ranges evenly. */
@@ -598,6 +605,62 @@ int oriana_trigamma_f64(double *y, const double *x, int64_t len, void *stream);
 int oriana_inverse_digamma_f64(double *y, const double *x, int64_t len, void *stream);
 int oriana_sigmoid_f64(double *y, const double *x, int64_t len, void *stream);
 int oriana_logit_f64(double *y, const double *x, int64_t len, void *stream);
+
+/* ---- [r5] planning of the resident layout as plain C (host arrays in and out, no device) -------------------------------
+ * What the kernels of a sweep depend on beyond the packed records.  engine.py (the Python host) and the resident handle below
+ * both call these; tests/test_plan.py checks them on the CPU against a NumPy restatement.
+ *
+ * oriana_plan_gene_order: the internal gene order.  Genes in decreasing order of their non-zero count (col_nnz, summed over
+ * all row shards; ties in the caller's order).  dense_density > 0 (hybrid layout): the genes expressed in at least that share
+ * of the n_total cells whose counts all fit a uint16 block (bad[j] == 0: no negative, >= 65535 or non-integer entry; bad may be
+ * NULL) come first, cut to a multiple of 32 (*gd), unless they hold less than min_share of the non-zeros (then *gd = 0). */
+int oriana_plan_gene_order(const int64_t *col_nnz, const int64_t *bad, int64_t m, int64_t n_total,
+                           double dense_density, double min_share, int32_t *order /* out [m] */, int64_t *gd /* out */);
+/* oriana_plan_col_work: the work list of oriana_col_pass -- items (column block, first row block, end row block) of about
+ * equal cost, ordered by row band (concurrent items stage the same factor rows).  tile_iters [nrb * ncb]: longest column-side
+ * slice of each tile in iterations of 64 slots; width = oriana_col_block_tiles(K); cost of a row block of a column block =
+ * 1.45 * (longest slice over its tiles; sum_price != 0: their sum) + 3.2 (staging 256 factor rows; microseconds on MI355X).
+ * target_items = 0: 25-50 tiles per item, 9 to 36 items per CU; rounds != 0: re-cut so that the count lands just below a
+ * multiple of `cus` (one 1024-thread group per CU: a partly filled last round costs a whole one).  items: out [cap][3],
+ * cap >= oriana_plan_col_work_capacity(nrb, ncb, width). */
+int64_t oriana_plan_col_work_capacity(int64_t nrb, int64_t ncb, int64_t width);
+int oriana_plan_col_work(const int32_t *tile_iters, int64_t nrb, int64_t ncb, int64_t width, int64_t cus,
+                         int64_t target_items, int rounds, int sum_price, int32_t *items, int64_t cap, int64_t *n_items);
+/* Splits of the dense-gene kernels of a hybrid layout: gene ranges of oriana_dense_row_pass (at most two work-groups per CU)
+ * and cell ranges of oriana_dense_col_pass (four per CU, a multiple of 8 cell tiles). */
+int oriana_plan_dense_splits(int64_t n, int64_t gd, int64_t cus, int64_t *gene_splits, int64_t *cell_splits);
+
+/* ---- [r5] resident handle: the count matrix packed ONCE for a host that is not Python --------------------------------------
+ * The reference calls its loop nest once per step() with the same X (oriana/models/gap.py:89-94, zigap.py:105-112,
+ * sparse_gap.py:107-115, sparse_zigap.py:126-135) and re-casts X every time; the stateless entries above repack X per call.
+ * A handle owns (hipMalloc) the packed layout -- gene order, sliced records, the dense uint16 block of a hybrid layout
+ * (dense_density > 0 and oriana_dense_supported(K); <= 0: sliced only), the column work list, the row split, the scratch of a
+ * call -- built by the planning functions above for oriana_device_cus() compute units.  X: dense (n, ldx) float32 on the
+ * DEVICE, or CSR on the HOST (indptr [n + 1], indices, data; expanded on the device in row chunks of at most 512 MB, so
+ * neither side ever holds the dense matrix; duplicate entries add up).  The create calls synchronise the stream; the zq
+ * calls are asynchronous on it, take DEVICE matrices in the reference's argument order (outputs first, zero-filled by the
+ * callee, 2-D C-contiguous float32) and must not run concurrently on one handle. */
+typedef struct oriana_resident oriana_resident;
+int oriana_counts_create_dense_f32(oriana_resident **out, const float *X, int64_t n, int64_t m, int64_t ldx, int64_t K,
+                                   double dense_density, void *stream);
+int oriana_counts_create_csr(oriana_resident **out, const int64_t *indptr, const int32_t *indices, const float *data,
+                             int64_t n, int64_t m, int64_t K, double dense_density, void *stream);
+int oriana_counts_destroy(oriana_resident *h);
+/* info[0..12] = {n, m, K, Kp, non-zeros, dense genes, row-side slots, column-side slots, resident bytes, column work items,
+ * row-split parts, first split row block, compute units planned for} */
+int oriana_counts_info(const oriana_resident *h, int64_t *info, int64_t len);
+/* GaP.compute_Z_q_expectations (gap.py:67-80) on the resident layout, sliced or hybrid. */
+int oriana_zq_gap_resident(oriana_resident *h, float *Z_hat_i, float *Z_hat_j, const float *log_U_hat, const float *log_V_hat,
+                           void *stream);
+/* The three twins (zigap.py:79-95, sparse_gap.py:81-97, sparse_zigap.py:100-116) on a resident SLICED layout (ORIANA_EINVAL for a
+ * hybrid handle); D_hat (n, m) is gathered at the stored entries on every call. */
+int oriana_zq_zigap_resident(oriana_resident *h, float *DZ_hat_i, float *DZ_hat_j, float *DZ_exp_logsum_hat,
+                             const float *log_U_hat, const float *log_V_hat, const float *D_hat, int reference_quirks, void *stream);
+int oriana_zq_sparse_gap_resident(oriana_resident *h, float *SZ_hat_i, float *Z_hat_j, float *Z_exp_logsum_hat,
+                                  const float *log_U_hat, const float *log_V_hat, const float *S_tilde, const float *S_hat, void *stream);
+int oriana_zq_sparse_zigap_resident(oriana_resident *h, float *DSZ_hat, float *DZ_hat, float *DZ_exp_logsum_hat,
+                                    const float *log_U_hat, const float *log_V_hat, const float *S_tilde, const float *S_hat,
+                                    const float *D_hat, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'dense_mfma.hip', 'dense_f32.hip', 'dense_pass.hip', 'dense_zi.hip', 'metrics.hip', 'stateless.hip']
+SOURCES = ['pack.hip', 'passes.hip', 'updates.hip', 'dense.hip', 'dense_mfma.hip', 'dense_f32.hip', 'dense_pass.hip', 'dense_zi.hip', 'metrics.hip', 'stateless.hip', 'resident.hip']
 LIB = os.path.join(CSRC, 'liboriana_hip.so')
 # dense_zi.hip: the loop body of k_zi_row<6, 1> is ONE fully unrolled basic block of ~2700 instructions (a hand-placed
 # slot plan of matrix and vector instructions); it exceeds the default size limit of `#pragma unroll`

@@ -60,6 +60,20 @@ _SIGS = {
     'oriana_row_pass_general': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, ctypes.POINTER(OrianaRowSplit), _P, _P]),
     'oriana_prep_den_threshold_offset': (_I, []),
     'oriana_row_pass_plan': (c_int, [ctypes.POINTER(OrianaCounts), _I, _P, ctypes.POINTER(OrianaRowSplit)]),
+    'oriana_row_pass_plan_cus': (c_int, [ctypes.POINTER(OrianaCounts), _I, _P, _I, ctypes.POINTER(OrianaRowSplit)]),
+    'oriana_device_cus': (_I, []),
+    'oriana_plan_gene_order': (c_int, [_P, _P, _I, _I, c_double, c_double, _P, _P]),
+    'oriana_plan_col_work_capacity': (_I, [_I, _I, _I]),
+    'oriana_plan_col_work': (c_int, [_P, _I, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
+    'oriana_plan_dense_splits': (c_int, [_I, _I, _I, _P, _P]),
+    'oriana_counts_create_dense_f32': (c_int, [_P, _P, _I, _I, _I, _I, c_double, _P]),
+    'oriana_counts_create_csr': (c_int, [_P, _P, _P, _P, _I, _I, _I, c_double, _P]),
+    'oriana_counts_destroy': (c_int, [_P]),
+    'oriana_counts_info': (c_int, [_P, _P, _I]),
+    'oriana_zq_gap_resident': (c_int, [_P, _P, _P, _P, _P, _P]),
+    'oriana_zq_zigap_resident': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    'oriana_zq_sparse_gap_resident': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'oriana_zq_sparse_zigap_resident': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_det_scratch_bytes': (c_int64, [_I, _I]),

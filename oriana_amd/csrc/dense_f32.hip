@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void k_dropout_sweep_b16(float *__restrict_
 // full one -- 1580 groups take 4 rounds at 77 %.  Among 4 to 12 rounds' worth, the count that leaves the last round
 // fullest (fewer ranges on ties: each one ends in a set of float64 atomics).
 static int64_t pick_splits(int64_t blocks, int64_t max_splits) {
-    const int64_t slots = 512;
+    const int64_t slots = 2 * oriana_device_cus();            // (512 on MI355X)
     int64_t best = 1;
     double best_eff = 0.0;
     for (int64_t sp = 1; sp <= max_splits && sp <= 4096; ++sp) {

@@ -557,15 +557,16 @@ static int zi_set_lds(KernelT kern, size_t bytes) {
     return 0;
 }
 
-// work-groups of 512 threads, one per CU: the split count that leaves the last round of 256 fullest (fewer on ties)
+// work-groups of 512 threads, one per CU: the split count that leaves the last round of the chip fullest (fewer on ties)
 static int64_t zi_pick_splits(int64_t blocks, int64_t max_splits) {
+    const int64_t cus = oriana_device_cus();                 // (256 on MI355X)
     int64_t best = 1;
     double best_eff = 0.0;
     for (int64_t sp = 1; sp <= max_splits && sp <= 64; ++sp) {
         const int64_t groups = blocks * sp;
-        if (groups > 16 * 256 && sp > 1) break;
-        const int64_t rounds = (groups + 255) / 256;
-        const double eff = (double)groups / (double)(rounds * 256);
+        if (groups > 16 * cus && sp > 1) break;
+        const int64_t rounds = (groups + cus - 1) / cus;
+        const double eff = (double)groups / (double)(rounds * cus);
         if (eff > best_eff + 0.03) { best_eff = eff; best = sp; }
     }
     return best;

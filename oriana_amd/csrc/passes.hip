@@ -1003,7 +1003,16 @@ __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const f
 // ------------------------------------------------------------------------------------------
 // fix-up: exact reference arithmetic for the entries flagged with the NaN sentinel
 // ------------------------------------------------------------------------------------------
-// grid = tiles; block = 256 threads striding over the row-side slots of a flagged tile.
+// grid = tiles; block = 256 threads.  [r5] A flagged tile is scanned in windows of 2048 row-side slots; the sentinels of a
+// window are queued in LDS and then evaluated by a WAVE each, lanes over the factors: the K exponentials of an entry run in
+// parallel and its additions to Z_i / Z_j / Z_log are contiguous K-vectors (one coalesced float atomic per wave and matrix).
+// Round 4 gave every sentinel to one THREAD: 2K expf in sequence and, at each k, 64 atomics of a wave to 64 different rows --
+// the slowest shape float atomics have on this part (guide: 64 lanes in 64 rows ~ 17 x slower than a contiguous 256 bytes).
+// After the reference's default NMF start a ZI-pCMF fit at configs[2] passes through sweeps with 5,600 of 30,889 tiles
+// flagged: 4 ms of slow path per sweep in that form.  The arithmetic of an entry is unchanged: expf of the float32 sum, den
+// added up LEFT TO RIGHT in float32 (every lane runs the same chain over the wave's LDS copy of the exponentials), the
+// den > 0 guard, (x e) / den.
+constexpr int FIX_WINDOW = 2048, FIX_KMAX = 256;
 __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *__restrict__ tile_flag,
                                                float *__restrict__ s_cs, float *__restrict__ sw_cs,
                                                float *__restrict__ s_rs, const float *__restrict__ logU,
@@ -1013,43 +1022,78 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
                                                float *__restrict__ Zj, float *__restrict__ Zlog, int K, int quirk) {
     const int64_t t = blockIdx.x;
     if (tile_flag[t] == 0) return;
+    __shared__ uint32_t queue[FIX_WINDOW];
+    __shared__ uint32_t rs[17];
+    __shared__ uint32_t qn;
+    __shared__ __attribute__((aligned(16))) float ebuf[4][FIX_KMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rb = t / cm.ncb, cb = t - rb * cm.ncb;
     const int64_t rbase = cm.roff[t], cbase = cm.coff[t];
-    for (int sl = 0; sl < 16; ++sl) {
-        const uint32_t s0 = cm.rslice[t * 17 + sl], s1 = cm.rslice[t * 17 + sl + 1];
-        for (uint32_t slot = s0 + threadIdx.x; slot < s1; slot += 256) {
+    if (tid < 17) rs[tid] = cm.rslice[t * 17 + tid];
+    __syncthreads();
+    const uint32_t total = rs[16];
+    const int K4 = (K + 3) & ~3;
+    for (uint32_t base = 0; base < total; base += FIX_WINDOW) {
+        if (tid == 0) qn = 0;
+        __syncthreads();
+        #pragma unroll
+        for (int u = 0; u < FIX_WINDOW / 256; ++u) {
+            const uint32_t slot = base + (uint32_t)u * 256u + (uint32_t)tid;
+            if (slot < total) {
+                const oriana_rowrec rec = cm.rowrec[rbase + slot];
+                if (rec.x != 0.f) {                                  // (0: padding)
+                    const float sv = s_cs[cbase + rec.cdst];
+                    if (sv != sv) queue[atomicAdd(&qn, 1u)] = slot;  // a sentinel
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nq = qn;
+        for (uint32_t q = wave; q < nq; q += 4) {
+            const uint32_t slot = queue[q];
+            int sl = 0;
+            #pragma unroll
+            for (int c = 1; c < 16; ++c) sl += (slot >= rs[c]) ? 1 : 0;
             const oriana_rowrec rec = cm.rowrec[rbase + slot];
-            if (rec.x == 0.f) continue;                              // padding
-            const float s = s_cs[cbase + rec.cdst];
-            if (s == s) continue;                                    // not a sentinel
-            const int rl = sl * 16 + (int)(((slot - s0) & 63u) >> 2);
+            const int rl = sl * 16 + (int)((slot & 63u) >> 2);       // (slices start at multiples of 64 slots)
             const int64_t ip = rb * TILE + rl;                       // packed row / column
             const int64_t jp = cb * TILE + rec.col;
             const int64_t i = cm.row_perm ? (int64_t)cm.row_perm[ip] : ip;   // caller's row / gene
             const int64_t j = cm.col_perm ? (int64_t)cm.col_perm[jp] : jp;
-            const float *lu = logU + i * K;
-            const float *lv = logV + j * K;
-            const float *st = S_tilde ? S_tilde + j * K : nullptr;
-            const float *sh = S_hat ? S_hat + j * K : nullptr;
             const float x = rec.x;
             const float w = w_nz ? w_nz[rbase + slot] : 1.0f;
+            float ls[FIX_KMAX / 64], e[FIX_KMAX / 64];
+            #pragma unroll
+            for (int r = 0; r < FIX_KMAX / 64; ++r) {
+                const int k = lane + 64 * r;
+                ls[r] = 0.f; e[r] = 0.f;
+                if (k < K) {
+                    ls[r] = logU[i * K + k] + logV[j * K + k];
+                    e[r] = expf(ls[r]);
+                    if (S_tilde) e[r] *= S_tilde[j * K + k];
+                }
+                if (k < K4) ebuf[wave][k] = e[r];                    // (zeros up to a multiple of 4: den + 0 = den)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the wave's own LDS writes, before its lanes read them)
+            __builtin_amdgcn_wave_barrier();
             // den = sum_k exp(lu + lv) [* S_tilde], float32, left to right (gap.py:74-76)
             float den = 0.f;
-            for (int k = 0; k < K; ++k) {
-                float e = expf(lu[k] + lv[k]);
-                if (st) e *= st[k];
-                den += e;
+            for (int k = 0; k < K4; k += 4) {
+                const f4 v = *reinterpret_cast<const f4 *>(&ebuf[wave][k]);
+                den += v.x; den += v.y; den += v.z; den += v.w;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (read before the next entry overwrites the copy)
+            __builtin_amdgcn_wave_barrier();
             den = (den > 0.f) ? den : 1.0f;
-            for (int k = 0; k < K; ++k) {
-                const float ls = lu[k] + lv[k];
-                float e = expf(ls);
-                if (st) e *= st[k];
-                const float expectation = (x * e) / den;            // gap.py:78
+            #pragma unroll
+            for (int r = 0; r < FIX_KMAX / 64; ++r) {
+                const int k = lane + 64 * r;
+                if (k >= K) continue;
+                const float expectation = (x * e[r]) / den;          // gap.py:78
                 if (Zi) {
                     float wi = w;
-                    if (sh) wi = w_nz ? w * sh[k] : sh[k];          // sparse_zigap.py:114 / sparse_gap.py:95
-                    const float v = (w_nz || sh) ? wi * expectation : expectation;
+                    if (S_hat) wi = w_nz ? w * S_hat[j * K + k] : S_hat[j * K + k];   // sparse_zigap.py:114 / sparse_gap.py:95
+                    const float v = (w_nz || S_hat) ? wi * expectation : expectation;
                     if (v != 0.f) atomicAdd(&Zi[i * K + k], v);
                 }
                 if (Zj) {
@@ -1061,14 +1105,17 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
                     if (v != 0.f) atomicAdd(&Zj[((quirk & 2) ? jp : j) * K + k], v);
                 }
                 if (Zlog) {
-                    const float v = (w_nz ? w * expectation : expectation) * ls;   // zigap.py:95
+                    const float v = (w_nz ? w * expectation : expectation) * ls[r];   // zigap.py:95
                     if (v != 0.f) atomicAdd(&Zlog[j * K + k], v);
                 }
             }
-            s_cs[cbase + rec.cdst] = 0.f;
-            if (sw_cs) sw_cs[cbase + rec.cdst] = 0.f;
-            if (s_rs) s_rs[rbase + slot] = 0.f;
+            if (lane == 0) {
+                s_cs[cbase + rec.cdst] = 0.f;
+                if (sw_cs) sw_cs[cbase + rec.cdst] = 0.f;
+                if (s_rs) s_rs[rbase + slot] = 0.f;
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -2596,34 +2643,35 @@ extern "C" int oriana_row_pass(const oriana_counts *cm, const float *FU, const f
 // matrix of 10,000 cells runs the pass on 40 of the 256 CUs; splitting each row block's gene tiles over several groups
 // fills the chip; each group of a row block stores its row sums in its own slab of R, which the consumer adds up
 // (atomics on R cost 1.2 us per split at 10,000 x 20: more than the tile a split saves).
-extern "C" int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const double *tile_cost, oriana_row_split *out) {
+extern "C" int oriana_row_pass_plan_cus(const oriana_counts *cm, int64_t K, const double *tile_cost, int64_t cus, oriana_row_split *out) {
+    if (cus <= 0) return ORIANA_EINVAL;
     if (!cm || !out || cm->nrb < 0 || cm->nrb > 0x7fffffffLL || cm->ncb > 0x7fffffffLL) return ORIANA_EINVAL;
     *out = no_split(cm);
     KCfg cfg;
     if (!pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 0;
     const bool two_lane = use_k100(cfg.G, cfg.T4) || (k64_kernels() && k64_cfg(cfg.G, cfg.T4, cfg.TAIL));
-    const int64_t groups = cm->nrb * ((two_lane || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (256 / (16 * (64 / cfg.G))));
+    const int64_t groups = cm->nrb * ((two_lane || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (TILE / (16 * (64 / cfg.G))));
     static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
     static const bool rounds_off = [] { const char *e = getenv("ORIANA_ROW_SPLIT_ROUNDS"); return e && !strcmp(e, "off"); }();
     int64_t nfull = 0, parts = 1;
     if (forced > 0) {
         parts = forced;
-    } else if (groups < 256) {
+    } else if (groups < cus) {
         // short matrices: two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20:
         // 77 / 42 / 25 / 24 us for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
-        parts = 512 / groups;
+        parts = 2 * cus / groups;
     } else if (two_lane && !rounds_off) {
-        // One 512-thread group per CU (the image and the registers leave room for one): the pass advances in rounds of 256
-        // row blocks and a partly filled last round costs a whole one (1M x 30k, K = 100: 3840 / 3907 / 4096 row blocks =
+        // One 512-thread group per CU (the image and the registers leave room for one): the pass advances in rounds of `cus`
+        // (256 on the MI355X the figures are from) row blocks and a partly filled last round costs a whole one (1M x 30k, K = 100: 3840 / 3907 / 4096 row blocks =
         // 33.9 / 35.8 / 36.2 ms; 391 row blocks -- configs[2] -- run as two rounds).  The row blocks of the last round are
         // split into p gene ranges each: ceil(tail * p / 256) / p rounds instead of one, + 1 % per extra range; a finer
         // split has to earn 3 %.
-        const int64_t tail = cm->nrb % 256;
+        const int64_t tail = cm->nrb % cus;
         if (tail == 0) return 0;
         double best = 1.0;
         int64_t bp = 1;
         for (int64_t p2 = 2; p2 <= 8 && p2 <= cm->ncb; ++p2) {
-            const double c = (double)((tail * p2 + 255) / 256) / (double)p2 + 0.01 * (double)(p2 - 1);
+            const double c = (double)((tail * p2 + cus - 1) / cus) / (double)p2 + 0.01 * (double)(p2 - 1);
             if (c < 0.97 * best) { best = c; bp = p2; }
         }
         if (bp == 1) return 0;
@@ -2661,6 +2709,11 @@ extern "C" int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const do
     }
     out->edge[parts] = (int32_t)cm->ncb;
     return 0;
+}
+
+// [r5] ... for the device the calling thread has selected (oriana_device_cus: multiProcessorCount, not a literal 256)
+extern "C" int oriana_row_pass_plan(const oriana_counts *cm, int64_t K, const double *tile_cost, oriana_row_split *out) {
+    return oriana_row_pass_plan_cus(cm, K, tile_cost, oriana_device_cus(), out);
 }
 
 // (round 3's interface: the number of gene ranges of a whole-grid split; 1 when the plan splits the last round only)

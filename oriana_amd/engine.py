@@ -72,8 +72,8 @@ class CountTiles:
         summed over all row shards): tiles then hold columns of similar density, which shortens
         the padding of the slices.  Internal only -- every dense input / output of the API stays
         in the caller's gene order."""
-        order = torch.argsort(col_nnz.to(self.device), descending=True, stable=True)
-        self.col_perm = order.to(torch.int32).contiguous()
+        order, _ = self.dense_order(col_nnz, 0, None, 0.0)
+        self.col_perm = order.to(self.device).to(torch.int32).contiguous()
 
     @staticmethod
     def dense_order(col_nnz, n_total, bad, density, min_share=0.0):
@@ -81,22 +81,17 @@ class CountTiles:
         are all integers in [0, 65535) (`bad`: per-gene number of entries that are not) come first, in decreasing
         order of their non-zero count, cut to a multiple of 32; the rest follows in decreasing order.  `min_share`: no
         dense block at all unless those genes hold at least this share of the non-zeros (the ZI / sparse models'
-        'auto': the block pays for them from about half-dense data on)."""
-        order = torch.argsort(col_nnz, descending=True, stable=True)
-        ok = (col_nnz.to(torch.float64) >= float(density) * max(int(n_total), 1)) & (bad == 0) & (col_nnz > 0)
-        ok_sorted = ok[order]
-        cand = order[ok_sorted]
-        gd = (int(cand.numel()) // 32) * 32
-        if gd and min_share > 0.0:
-            tot = float(col_nnz.sum().item())
-            if tot <= 0.0 or float(col_nnz[cand[:gd]].sum().item()) < float(min_share) * tot:
-                gd = 0
-        if gd == 0:
-            return order, 0
-        keep = torch.ones(order.numel(), dtype=torch.bool, device=order.device)
-        keep[cand[:gd]] = False
-        rest = order[keep[order]]
-        return torch.cat([cand[:gd], rest]), gd
+        'auto': the block pays for them from about half-dense data on).  The decision itself is
+        oriana_plan_gene_order (csrc/resident.hip: host code of the C ABI, shared with the resident handle)."""
+        dev = col_nnz.device
+        cn = np.ascontiguousarray(col_nnz.detach().cpu().numpy().astype(np.int64))
+        bd = np.ascontiguousarray(bad.detach().cpu().numpy().astype(np.int64)) if bad is not None else None
+        m = int(cn.shape[0])
+        order = np.empty(max(m, 1), dtype=np.int32)
+        gd = ctypes.c_int64(0)
+        call('oriana_plan_gene_order', cn.ctypes.data, bd.ctypes.data if bd is not None else None, m, int(n_total),
+             float(density or 0.0), float(min_share or 0.0), order.ctypes.data, ctypes.addressof(gd))
+        return torch.from_numpy(order[:m].astype(np.int64)).to(dev), int(gd.value)
 
     def _permute(self, chunk, r0=None, learn=False):
         """Apply the internal orderings to a dense row chunk: genes by col_perm; cells, inside the chunk,
@@ -170,62 +165,24 @@ class CountTiles:
         block: ordering the items by row range keeps the band being worked on in L2 / Infinity Cache --
         column pass 26.4 -> 25.0 ms at C4 against a longest-first order).  Cost of a tile = its longest column slice (the
         workgroup advances at the pace of its slowest wave) plus a fixed charge for staging the 256
-        factor rows (measured on MI355X: ~1.45 us per slice iteration, ~3.2 us per tile)."""
+        factor rows (measured on MI355X: ~1.45 us per slice iteration, ~3.2 us per tile).  The cut itself is
+        oriana_plan_col_work (csrc/resident.hip: host code of the C ABI, for the compute units of the device at hand)."""
         nt = self.nrb * self.ncb
         if nt == 0 or self.cslots == 0:
             return None
         cs = self.cslice[:nt * 17].view(nt, 17).to(torch.int64)
         nit = ((cs[:, 1:] - cs[:, :-1]) // 64).max(dim=1).values                     # longest slice per tile
-        nit = nit.view(self.nrb, self.ncb).cpu().numpy().astype(np.float64)
-        nblk = (self.ncb + width - 1) // width
-        if width > 1:
-            # the kernel walks the tiles of a block one after the other, so the SUM of the two slice lengths would be the
-            # honest price (ADVICE r2); with the constants below -- fitted to the maximum -- the sum measured 2.6 % slower on
-            # the column pass at C4 (14.84 against 14.46 ms, ORIANA_COL_PRICE=sum): the maximum stays
-            pad = np.zeros((self.nrb, nblk * width - self.ncb))
-            nit = np.concatenate([nit, pad], axis=1).reshape(self.nrb, nblk, width)
-            nit = nit.sum(axis=2) if os.environ.get('ORIANA_COL_PRICE') == 'sum' else nit.max(axis=2)
-        cost = nit * 1.45 + 3.2
-        total = float(cost.sum())
-        explicit_target = target_items
-        if target_items is None:
-            # 25-50 tiles per item (each item ends with one atomic flush of its accumulators), at least 9 per CU
-            target_items = min(9216, max(2304, nt // (50 * width)))
-        cums = [np.concatenate([[0.0], np.cumsum(cost[:, cb])]) for cb in range(nblk)]
-
-        def build(n_items):
-            target = max(total / n_items, 1e-9)
-            out = []
-            for cb in range(nblk):
-                cum = cums[cb]
-                nb = int(min(self.nrb, max(1, round(cum[-1] / target))))
-                # cut the column block at equal-cost points
-                edges = np.unique(np.searchsorted(cum, np.linspace(0.0, cum[-1], nb + 1)[1:-1], side='left'))
-                edges = np.concatenate([[0], edges, [self.nrb]]).astype(np.int64)
-                for a, e in zip(edges[:-1], edges[1:]):
-                    if e > a:
-                        out.append((cum[e] - cum[a], cb, int(a), int(e)))
-            return out
-        items = build(target_items)
-        # One 1024-thread group per CU and items of about equal cost: the pass advances in rounds of 256 items, and a partly
-        # filled last round costs a whole one.  Re-cut with slightly fewer items so that the count lands just below a
-        # multiple of 256 (ORIANA_COL_ROUNDS=off: the first cut).
-        if explicit_target is None and len(items) > 256 and os.environ.get('ORIANA_COL_ROUNDS', 'on') != 'off':
-            want = (len(items) // 256) * 256
-            t = target_items
-            trial = items
-            for _ in range(8):
-                if want - 24 <= len(trial) <= want:
-                    items = trial
-                    break
-                t = max(256, int(round(t * (want - 8) / max(len(trial), 1))))
-                trial = build(t)
-            else:
-                if want - 24 <= len(trial) <= want:
-                    items = trial
-        items.sort(key=lambda x: (x[2] + x[3], x[1]))          # by row band: concurrent items share factor rows
-        arr = np.asarray([[c, a, e] for _, c, a, e in items], dtype=np.int32)
-        return torch.from_numpy(arr).to(self.device).contiguous()
+        nit = np.ascontiguousarray(nit.cpu().numpy().astype(np.int32))
+        lib = _lib.load()
+        cap = int(lib.oriana_plan_col_work_capacity(self.nrb, self.ncb, int(width)))
+        items = np.empty((max(cap, 1), 3), dtype=np.int32)
+        n_items = ctypes.c_int64(0)
+        # (the pair's price: the maximum of the two slices; with the constants fitted to it the sum measured 2.6 % slower on
+        #  the column pass at C4, ORIANA_COL_PRICE=sum.  ORIANA_COL_ROUNDS=off: the first cut, not re-cut to whole rounds)
+        call('oriana_plan_col_work', nit.ctypes.data, self.nrb, self.ncb, int(width), int(lib.oriana_device_cus()),
+             int(target_items or 0), 0 if os.environ.get('ORIANA_COL_ROUNDS', 'on') == 'off' else 1,
+             1 if os.environ.get('ORIANA_COL_PRICE') == 'sum' else 0, items.ctypes.data, cap, ctypes.addressof(n_items))
+        return torch.from_numpy(items[:int(n_items.value)].copy()).to(self.device).contiguous()
 
     def col_work_for(self, K):
         """The work list matching the column tiles per work-group of the kernel that serves this K (cached)."""
@@ -560,12 +517,11 @@ class ZWorkspace:
             pv, pu = int(lib.oriana_dense_image_pieces(K, 0)), int(lib.oriana_dense_image_pieces(K, 1))
             self.dn_imgV = torch.empty(d.ngt * pv * 4, **f32)
             self.dn_imgU = torch.empty(max((ct.n + 31) // 32, 1) * pu * 4, **f32)
-            nblk = max(d.nct // 8, 1)
-            self.dn_gene_splits = max(1, min(d.ngt, -(-512 // nblk)))
+            gsp, csp = ctypes.c_int64(1), ctypes.c_int64(1)
+            call('oriana_plan_dense_splits', ct.n, d.gd, int(lib.oriana_device_cus()), ctypes.addressof(gsp), ctypes.addressof(csp))
+            self.dn_gene_splits, self.dn_cell_splits = int(gsp.value), int(csp.value)
             if os.environ.get('ORIANA_DN_GENE_SPLITS'):                     # tuning runs
                 self.dn_gene_splits = max(1, min(d.ngt, int(os.environ['ORIANA_DN_GENE_SPLITS'])))
-            groups = (d.ngt + 7) // 8
-            self.dn_cell_splits = max(1, min((ct.n + 31) // 32, (-(-1024 // groups) + 7) // 8 * 8))
 
     def dense_tail(self, nslab):
         """(first split 256-cell block, parts) of the dense row kernel: the split of the sliced row pass's last round when the

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
             const int idx = blk - tail_nfull, q = idx / tail_parts, part = idx - q * tail_parts;
             blk = tail_nfull + q;
             gt0 = (int)((int64_t)part * ngt / tail_parts); gt1 = (int)(((int64_t)part + 1) * ngt / tail_parts);
-            R += (int64_t)part * n * Kp;
+            R += (int64_t)part * (n - (int64_t)tail_nfull * 256) * Kp;      // (compact slabs: the rows from the first split block on)
         }
     }
     const int64_t ct = (int64_t)blk * NW + w;                              // this wave's cell tile

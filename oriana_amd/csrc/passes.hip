@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256) void k_finalize(float *__restrict__ Z, const f
     const float f = F[row * Kp + k];
     float rr = R[row * Kp + k];
     const int ns = row >= slab_row0 ? nslab : 1;                                        // (oriana_row_split: full row blocks have slab 0 only)
-    for (int sl = 1; sl < ns; ++sl) rr += R[((int64_t)sl * r + row) * Kp + k];         // oriana_row_pass_split
+    for (int sl = 1; sl < ns; ++sl) rr += R[((int64_t)sl * (r - slab_row0) + row) * Kp + k];         // oriana_row_pass_split
     float v = f * rr;
     if (mul) v *= mul[o];
     // (+ 0: a dead factor row is -0.0; the outputs carry +0.  The accumulating form without a multiplier is spelled as
@@ -1365,7 +1365,8 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n && !SROW) {
-        float *Rs = R + (int64_t)item.slab * cm.n * KP;
+        // (slab p >= 1 holds the rows of the split row blocks only: stride (n - 256 nfull) rows)
+        float *Rs = R + (int64_t)item.slab * (cm.n - (int64_t)split.nfull * TILE) * KP;
         #pragma unroll
         for (int t = 0; t < T4; ++t) reinterpret_cast<f4 *>(Rs)[row * KP4 + gchunk(lane, t)] = acc[t];
         if (TAIL) *reinterpret_cast<f2 *>(Rs + row * KP + 96 + 2 * q) = acct;
@@ -1804,7 +1805,8 @@ __global__ __launch_bounds__(512) void k_row_pass_k64(oriana_counts cm, const fl
         if (__any(bad) && lane == 0) tile_flag[t] = 1;
     }
     if (row < cm.n && !SROW) {
-        float *Rs = R + (int64_t)item.slab * cm.n * KP;
+        // (slab p >= 1 holds the rows of the split row blocks only: stride (n - 256 nfull) rows)
+        float *Rs = R + (int64_t)item.slab * (cm.n - (int64_t)split.nfull * TILE) * KP;
         #pragma unroll
         for (int t = 0; t < T4; ++t)
             if (lidx[t] < KP4) reinterpret_cast<f4 *>(Rs)[row * KP4 + lidx[t]] = acc[t];

@@ -516,7 +516,8 @@ int resident_build(oriana_resident *h, ChunkSource &src, double dense_density, h
     const int64_t Kp = h->Kp;
     RES_TRY(dev_alloc(h, &h->FU, (size_t)(std::max<int64_t>(n, 1) * Kp), true, s));
     RES_TRY(dev_alloc(h, &h->FV, (size_t)(std::max<int64_t>(m, 1) * Kp), true, s));
-    RES_TRY(dev_alloc(h, &h->R, (size_t)(h->nslab * std::max<int64_t>(n, 1) * Kp), true, s));
+    // (slabs 1.. of a last-round split hold the rows of the split row blocks only)
+    RES_TRY(dev_alloc(h, &h->R, (size_t)((std::max<int64_t>(n, 1) + (h->nslab - 1) * (n - (int64_t)h->split.nfull * TILE)) * Kp), true, s));
     RES_TRY(dev_alloc(h, &h->C, (size_t)(std::max<int64_t>(m, 1) * Kp), true, s));
     RES_TRY(dev_alloc(h, &h->s_cs, (size_t)std::max<int64_t>(h->cslots, 1), true, s));      // (padding slots must stay 0)
     RES_TRY(dev_alloc(h, &h->prep, (size_t)(oriana_prep_scratch_bytes() / 4), true, s));
@@ -596,7 +597,7 @@ extern "C" int oriana_zq_gap_resident(oriana_resident *h, float *Z_i, float *Z_j
     cl.ptr[e] = Z_j; cl.bytes[e++] = (int64_t)sizeof(float) * m * K;
     cl.ptr[e] = h->C; cl.bytes[e++] = (int64_t)sizeof(float) * m * Kp;
     cl.ptr[e] = h->tile_flag; cl.bytes[e++] = (int64_t)sizeof(int32_t) * std::max<int64_t>(h->nt, 1);
-    if (h->ms == 0) { cl.ptr[e] = h->R; cl.bytes[e++] = (int64_t)sizeof(float) * h->nslab * n * Kp; }
+    if (h->ms == 0) { cl.ptr[e] = h->R; cl.bytes[e++] = (int64_t)sizeof(float) * (n + (h->nslab - 1) * (n - (int64_t)h->split.nfull * TILE)) * Kp; }
     RES_TRY(oriana_factor_prep_pair_clear(h->FU, h->FV, log_U_hat, log_V_hat, nullptr, nullptr, h->col_perm, n, m, K, h->prep, &cl, stream));
     float *FVs = h->FV + gd * Kp, *Cs = h->C + gd * Kp;
     if (h->ms > 0)

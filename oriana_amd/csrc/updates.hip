@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
                 if (FIN) {
                     float rr = Rs[row * Kp + k];
                     const int ns = row >= slab_row0 ? nslab : 1;
-                    for (int sl = 1; sl < ns; ++sl) rr += Rs[((int64_t)sl * r + row) * Kp + k];
+                    for (int sl = 1; sl < ns; ++sl) rr += Rs[((int64_t)sl * (r - slab_row0) + row) * Kp + k];
                     const float zf = fmaf(F[row * Kp + k], rr, Zfin[idx]) + 0.0f;                  // k_finalize (accumulate)
                     Zfin[idx] = zf;
                     s1 = clamp_eps(prior1[k] + (double)zf);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
                 const int ns = row >= A.slab_row0 ? A.nslab : 1;
                 for (int sl = 1; sl < ns; ++sl) {
                     float r2[VEC];
-                    ld_f32<VEC>(r2, A.Rs + ((int64_t)sl * r + row) * Kp + k0);
+                    ld_f32<VEC>(r2, A.Rs + ((int64_t)sl * (r - A.slab_row0) + row) * Kp + k0);
                     #pragma unroll
                     for (int v = 0; v < VEC; ++v) rr[v] += r2[v];
                 }

@@ -155,8 +155,16 @@ class SweepExchange:
         if not self.active:
             return
         self.n_reduces += 1
-        bufs = [self.buf] if (self.numel32 and not self._parts32) else []
+        bufs = []
+        if self.numel32 and not self._parts32:
+            bufs.append(self.buf)
+        elif self.numel32:
+            # segments were sent early (reduce_rows_async): whatever they did NOT cover is reduced now -- an uncovered
+            # range would otherwise enter the gene-side update as this rank's partial sums and the ranks would diverge
+            for a, b in self._uncovered():
+                bufs.append(self.buf[a:b])
         self._parts32 = False
+        self._covered = []
         if self.numel64 and not self._started64:
             bufs.append(self.buf64)
         self._started64 = False
@@ -197,11 +205,24 @@ class SweepExchange:
 
     _started64 = False
     _parts32 = False
+    _covered = ()
+
+    def _uncovered(self):
+        """Ranges [a, b) of the float32 buffer (in elements) that no reduce_rows_async call of this exchange has sent."""
+        out, pos = [], 0
+        for a, b in sorted(self._covered):
+            if a > pos:
+                out.append((pos, a))
+            pos = max(pos, b)
+        if pos < self.numel32:
+            out.append((pos, self.numel32))
+        return out
 
     def reduce_rows_async(self, name, lo, hi):
         """Start the all-reduce of rows [lo, hi) of the float32 segment `name` NOW, asynchronously (the segment is written
         in an order that makes them final early: engine.zq_gap zj_packed).  The next reduce() then sends no float32 buffer
-        and only waits.  A sweep that uses this must cover every row of every float32 segment with such calls."""
+        and only waits for them -- plus, should the calls of a sweep not cover every row of every float32 segment, one
+        all-reduce per uncovered range."""
         if not self.active or hi <= lo:
             return
         o, c, shape = self._seg32[name]
@@ -210,6 +231,9 @@ class SweepExchange:
         self._pending.append(dist.all_reduce(self.buf[o + lo * width:o + hi * width], op=dist.ReduceOp.SUM, group=self.pg,
                                              async_op=True))
         self._parts32 = True
+        if not isinstance(self._covered, list):
+            self._covered = []
+        self._covered.append((o + lo * width, o + hi * width))
 
     def start64(self):
         """Start the float64 all-reduce NOW, asynchronously: its partials (the cell-side column sums, D_hat^T U_hat)

@@ -506,7 +506,7 @@ class ZWorkspace:
         self.row_gene_splits = int(self.row_split.parts)
         self.row_slab_row0 = int(self.row_split.nfull) * TILE
         gs = self.row_gene_splits
-        self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32) if gs == 1 else torch.zeros(gs, ct.n, self.Kp, **f32)
+        self.R = self._alloc_R(gs, self.row_slab_row0)
         if ct.dense is not None:
             if not dense_supported(K):
                 raise _lib.OrianaHipError('K=%d has no dense-gene kernels (oriana_dense_supported): pack without dense_density' % K)
@@ -522,6 +522,14 @@ class ZWorkspace:
             self.dn_gene_splits, self.dn_cell_splits = int(gsp.value), int(csp.value)
             if os.environ.get('ORIANA_DN_GENE_SPLITS'):                     # tuning runs
                 self.dn_gene_splits = max(1, min(d.ngt, int(os.environ['ORIANA_DN_GENE_SPLITS'])))
+
+    def _alloc_R(self, parts, row0):
+        """The row sums: slab 0 for every row; slabs 1 .. parts - 1 for the rows from `row0` on only (the row blocks of the
+        last round that the plan splits; a whole-grid split has row0 = 0) -- the kernels address slab p at a stride of
+        n - row0 rows, so the buffer is (n + (parts - 1)(n - row0)) rows (0.8 GB less at C4 than `parts` full slabs)."""
+        n = max(self.ct.n, 1)
+        rows = n + (parts - 1) * max(self.ct.n - int(row0), 0)
+        return torch.zeros(rows, self.Kp, dtype=torch.float32, device=self.ct.device)
 
     def dense_tail(self, nslab):
         """(first split 256-cell block, parts) of the dense row kernel: the split of the sliced row pass's last round when the
@@ -546,8 +554,7 @@ class ZWorkspace:
                 sp.edge[i] = int(e)
         self.row_gene_splits = int(parts)
         self.row_slab_row0 = int(nfull) * TILE
-        f32 = dict(dtype=torch.float32, device=ct.device)
-        self.R = torch.zeros(max(ct.n, 1), self.Kp, **f32) if parts == 1 else torch.zeros(parts, ct.n, self.Kp, **f32)
+        self.R = self._alloc_R(int(parts), self.row_slab_row0)
 
     def prep_outputs(self, packed_rows):
         """(FU_next, mu, upart) for oriana_gamma_update[_finalize]_prep, or None when the cell side's Gamma update cannot

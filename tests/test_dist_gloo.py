@@ -192,6 +192,19 @@ def _segment_worker(rank, world, port, out):
         xch.put64('sumU', torch.from_numpy(sums))
         xch.reduce()
         assert xch.n_reduces == 2 and xch.n_collectives == 5
+        # [r5] a PARTIAL cover (a model with a second float32 segment that only sends part of the first one early): what the
+        # early calls did not send is reduced by reduce() itself -- no rank keeps unreduced per-gene sums
+        x2 = odist.SweepExchange('cpu', dist.group.WORLD, {'Zj': (m, K), 'Zlog': (m, K)}, {'sumU': (2, K)})
+        x2.f32['Zj'].copy_(torch.from_numpy(zj)); x2.f32['Zlog'].copy_(torch.from_numpy(2 * zj))
+        x2.put64('sumU', torch.from_numpy(sums))
+        x2.reduce_rows_async('Zj', gd, m)
+        before = x2.n_collectives
+        x2.reduce()
+        assert x2.n_collectives == before + 3                     # Zj[:gd], the whole of Zlog, the float64 buffer
+        z_all = [None] * world
+        dist.all_gather_object(z_all, zj)
+        tot = sum(z.astype(np.float64) for z in z_all)
+        assert np.allclose(x2.f32['Zj'].numpy(), tot, rtol=3e-7) and np.allclose(x2.f32['Zlog'].numpy(), 2 * tot, rtol=3e-7)
         gathered = [None] * world
         dist.all_gather_object(gathered, dict(Zj=zj, sumU=sums))
         if rank == 0:

@@ -63,11 +63,12 @@ def test_update_with_prep_outputs_matches_separate_preparation(eng, r, K, form):
                  ptr(Z), None, ptr(rate), None, None, r, K, prep[0], prep[1], prep[2], st)
         else:
             F = torch.ones(r, Kp, device=dev)
-            R = torch.zeros(2, r, Kp, device=dev)
-            R[0, :, :K] = Z * 0.75
-            R[1, :, :K] = Z * 0.25
-            R[1, :r // 2] = 0.0
-            R[0, :r // 2, :K] = Z[:r // 2]
+            # slab 0: every row; slab 1: the rows from r // 2 on only (stride r - r // 2 rows, oriana_finalize_slabs_from)
+            row0 = r // 2
+            R = torch.zeros(r + (r - row0), Kp, device=dev)
+            R[:r, :K] = Z * 0.75
+            R[:row0, :K] = Z[:row0]
+            R[r:, :K] = Z[row0:] * 0.25
             Zf = torch.zeros(r, K, device=dev)
             call('oriana_gamma_update_finalize_prep', ptr(a1), ptr(a2), ptr(E), ptr(El), ptr(sums[0]), ptr(sums[1]), ptr(p1), ptr(p2),
                  ptr(Zf), ptr(F), ptr(R), 2, r // 2, None, ptr(rate), r, K, prep[0], prep[1], prep[2], st)

@@ -143,12 +143,13 @@ def test_gene_split_rule(eng):
     # [r4] the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100) split the row blocks of a partly filled LAST round of
     # the chip: 391 row blocks = 256 whole + 135 in five gene ranges (3 / 5 of a round); 489 = 256 + 233: two rounds anyway
     import os
-    if os.environ.get('ORIANA_ROW_SPLIT_ROUNDS') != 'off' and not os.environ.get('ORIANA_PASS_IMPL'):
+    if os.environ.get('ORIANA_ROW_SPLIT_ROUNDS') != 'off':
         c3 = eng.CountTiles.from_scipy(sp.random(100000, 1200, density=0.004, format='csr', random_state=3, dtype=np.float32), 'cuda')
         assert c3.nrb == 391 and c3.ncb == 5
         for K in (50, 100):                                                      # the 135 row blocks of the second round in 5 ranges
             w = eng.ZWorkspace(c3, K)
-            assert (w.row_split.nfull, w.row_split.parts, w.row_slab_row0) == (256, 5, 65536) and w.R.shape[0] == 5
+            assert (w.row_split.nfull, w.row_split.parts, w.row_slab_row0) == (256, 5, 65536)
+            assert w.R.shape[0] == 100000 + 4 * (100000 - 65536)          # slab 0 for every row, slabs 1-4 for the split row blocks only
             assert list(w.row_split.edge[:6]) == [0, 1, 2, 3, 4, 5]
         assert eng.ZWorkspace(c3, 20).row_gene_splits == 1                       # (narrow kernels: several groups per CU)
         c8 = eng.CountTiles.from_scipy(sp.random(125000, 1200, density=0.004, format='csr', random_state=4, dtype=np.float32), 'cuda')

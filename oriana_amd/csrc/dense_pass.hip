@@ -29,13 +29,7 @@
 namespace oriana {
 namespace dn {
 
-#ifdef ORIANA_DN_STAMP
-// analysis build: cycle stamps of one wave per work-group of k_dn_row, summed over the tiles and printed
-#define DN_STAMP(K) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-                         stamp_acc[K] += t_ - stamp_last; stamp_last = t_; } while (0)
-#else
 #define DN_STAMP(K) do { } while (0)
-#endif
 
 // One work-group per tile of 32 factor rows (genes or cells); F is a padded (rows, Kp) float32 factor matrix.  F2: the
 // matrix the SECOND image (the B operand of the accumulation, and its tail pieces) is taken from -- the sparse models
@@ -165,9 +159,6 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
 
     f16v rs[NT];                         // R of the strip: [cell acc_row(v, h)][factor 32 nt + c]
     f4v rt = {0.f, 0.f, 0.f, 0.f};       // tail factors: 4 x 4 blocks (cells x factors), this half's genes
-#ifdef ORIANA_DN_ABL_RT4
-    f4v rt4[4] = {rt, rt, rt, rt};
-#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -216,10 +207,6 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
     uint32_t fl = 0;                     // slow-path flags of the wave's tiles (see item 17)
     constexpr int NA = KC * 6 + (TAIL ? 2 : 0);                            // matrix instructions of D
     constexpr int NB = NT * 12;                                            // ... of R
-#ifdef ORIANA_DN_STAMP
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
-#endif
     for (int gt = gt0; gt < gt1; ++gt) {
         const int bufn = (buf == 2) ? 0 : buf + 1, bufnn = (buf == 0) ? 2 : buf - 1;
         const u4v *im1 = img + bufn * C::PV;                               // tile gt + 1: D
@@ -235,12 +222,6 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         // ================= stage A: the matrix instructions of D(gt + 1), one per slot; beside them S(gt), the splits of
         // s and R's tail products
         bool allok = true;
-#ifdef ORIANA_DN_ABL_VAND
-        uint32_t okbits = 0xFFFFFFFFu;
-#endif
-#ifdef ORIANA_DN_ABL_PKMUL
-        float pk_x = 0.f, pk_r = 0.f; bool pk_ok = true;
-#endif
         f4v tq[4];
         u4v a2[2][3];
         uint32_t sh = 0, sm = 0, sl = 0;                                   // bf16 parts of the even value of a pair
@@ -275,46 +256,17 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
 #pragma unroll
             for (int it = (u * NITEM) / NA; it < ((u + 1) * NITEM) / NA; ++it) {
                 if (it < 16) {
-#ifndef ORIANA_DN_ABL_NOS
                     const int v = it;
                     const uint32_t wd = xn[v >> 3][(v & 7) >> 1];
                     const uint32_t xi = (v & 1) ? (wd >> 16) : (wd & 0xFFFFu);
                     const float den = l0[v];
                     const bool ok = den >= den_min;                        // false for 0, tiny and NaN
-#ifdef ORIANA_DN_ABL_VAND
-                    okbits &= ok ? 0xFFFFFFFFu : 0u;               /* analysis switch: the running test on the vector ALU */
-#elif !defined(ORIANA_DN_ABL_NOAND)
                     allok = allok && ok;
-#endif
                     // branch-free: a failed test leaves the NaN sentinel in the stored tile (also where x == 0: the
                     // slow path clears it) and 0 in the registers that feed R
-#ifdef ORIANA_DN_ABL_NORCP
-                    const float t = (float)xi * (ok ? den : NAN);
-#elif defined(ORIANA_DN_ABL_PKMUL)
-                    // analysis switch: the multiplications of a pair of values as one v_pk_mul_f32
-                    float t;
-                    if ((v & 1) == 0) { pk_x = (float)xi; pk_r = ok ? __builtin_amdgcn_rcpf(den) : NAN; t = 0.f; }
-                    else {
-                        typedef float f2p __attribute__((ext_vector_type(2)));
-                        f2p a_ = {pk_x, (float)xi}, b_ = {pk_r, ok ? __builtin_amdgcn_rcpf(den) : NAN}, c_;
-                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(c_) : "v"(a_), "v"(b_));
-                        t = c_.y;
-                        Tw[(8 * ((v - 1) >> 2) + ((v - 1) & 3)) * TS] = c_.x;
-                        l0[v - 1] = pk_ok ? c_.x : 0.f;
-                    }
-                    if ((v & 1) == 0) pk_ok = ok;
-#else
                     const float t = (float)xi * (ok ? __builtin_amdgcn_rcpf(den) : NAN);
-#endif
-#ifdef ORIANA_DN_ABL_PKMUL
-                    if (v & 1) { Tw[(8 * (v >> 2) + (v & 3)) * TS] = t; l0[v] = ok ? t : 0.f; }
-#else
-#ifndef ORIANA_DN_ABL_NODSW
                     Tw[(8 * (v >> 2) + (v & 3)) * TS] = t;
-#endif
                     l0[v] = ok ? t : 0.f;
-#endif
-#endif
                 } else if (it == 16) {
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -323,25 +275,15 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                     // middle of the matrix work, not at the top of the iteration: measured 4-10 % faster (the copies then
                     // do not compete with the first operand reads after the barrier)
                     const int g2 = (gt + 2 < gt1) ? gt + 2 : gt1 - 1;
-#ifndef ORIANA_DN_ABL_NODMA
                     image_dma<C::PV>(imgV + (int64_t)g2 * C::PV, img + bufnn * C::PV, w, lane);
-#endif
                 } else if (it == 17) {
                     float *sblk = srow + (int64_t)gt * 1024;
-#ifndef ORIANA_DN_ABL_NOSTORE
 #pragma unroll
                     for (int q = 0; q < 4; ++q) reinterpret_cast<f4v *>(sblk)[q * 64 + lane] = tq[q];
                     // one flag per (cell tile, gene tile): lane (t mod 64) keeps bit t / 64 of its tile t = gt - gt0 and
                     // the flags leave after the loop (no store, no branch here)
-#ifdef ORIANA_DN_ABL_VAND
-                    allok = okbits != 0u;
-#endif
                     fl |= (__any(!allok) && lane == ((gt - gt0) & 63)) ? (1u << ((gt - gt0) >> 6)) : 0u;
-#else
-                    if (tq[0].x == 12345.f && __any(!allok)) reinterpret_cast<f4v *>(sblk)[lane] = tq[1] + tq[2] + tq[3];
-#endif
                 } else if (it < 34) {
-#ifndef ORIANA_DN_ABL_NOSPLIT
                     // split of value vv (three bf16 parts, exact); pairs are packed into the A operand of R
                     const int vv = it - 18;
                     const float x0 = l0[vv];
@@ -354,11 +296,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                         // 4 (b % 8) + i (this lane's value), B[b][j] = FV[gene][KM + j]: exact float32 FMAs on the matrix pipe
                         // (the B operands of four values at a time: 4 registers in flight instead of 16)
                         if ((vv & 3) == 0) t2 = tails[32 + (h * 4 + (lane & 3)) * 4 + (vv >> 2)];
-#ifdef ORIANA_DN_ABL_RT4
-                        rt4[vv & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, t2[vv & 3], rt4[vv & 3], 0, 0, 0);   /* analysis switch */
-#else
                         rt = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, t2[vv & 3], rt, 0, 0, 0);
-#endif
                     }
                     if ((vv & 1) == 0) { sh = b0; sm = c0; sl = __float_as_uint(s0); }
                     else {
@@ -367,16 +305,11 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
                         a2[q][1][w2] = __builtin_amdgcn_perm(c0, sm, 0x07060302u);
                         a2[q][2][w2] = __builtin_amdgcn_perm(__float_as_uint(s0), sl, 0x07060302u);
                     }
-#endif
                 } else {
                     // the counts of tile gt + 1 (this tile's were consumed by the items 0..15)
                     const int g1 = (gt + 1 < gt1) ? gt + 1 : gt1 - 1;
-#ifndef ORIANA_DN_ABL_NOX
                     xn[0] = reinterpret_cast<const u4v *>(xrow + (int64_t)g1 * 1024)[lane];
                     xn[1] = reinterpret_cast<const u4v *>(xrow + (int64_t)g1 * 1024)[64 + lane];
-#else
-                    (void)g1;
-#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -412,12 +345,7 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
             __builtin_amdgcn_sched_barrier(0);
             if (u % 12 == 11) {          // the 32-gene partial sums join the running sums (float32, round to nearest)
 #pragma unroll
-#ifdef ORIANA_DN_ABL_SCALAR_ADD
-                // analysis switch: the 48 additions as scalar v_add_f32 (the compiler packs them into v_pk_add_f32)
-                for (int v = 0; v < 16; ++v) { float r_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r_) : "v"(rs[nt][v]), "v"(dv[v])); rs[nt][v] = r_; }
-#else
                 for (int v = 0; v < 16; ++v) rs[nt][v] += dv[v];
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -427,17 +355,10 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DN_STAMP(5);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef ORIANA_DN_ABL_NOBAR
         __builtin_amdgcn_s_barrier();
-#endif
         DN_STAMP(6);
         buf = bufn;
     }
-#ifdef ORIANA_DN_STAMP
-    if (lane == 0 && (blk % 61) == 7 && (w == 0 || w == 5))
-        printf("stamp blk %d w %d tiles %d: top->s15 %llu  s16-17 %llu  rest of A %llu  B %llu  vmcnt %llu  barrier %llu  (head %llu)\n", blk, w, gt1 - gt0,
-               stamp_acc[1] / (gt1 - gt0), stamp_acc[2] / (gt1 - gt0), stamp_acc[3] / (gt1 - gt0), stamp_acc[4] / (gt1 - gt0), stamp_acc[5] / (gt1 - gt0), stamp_acc[6] / (gt1 - gt0), stamp_acc[0]);
-#endif
     // ---- the flags of the strip's tiles (every entry of flag[ct][gt0 .. gt1) is written)
     for (int j = 0; gt0 + 64 * j < gt1; ++j) {
         const int gt = gt0 + 64 * j + lane;
@@ -457,9 +378,6 @@ __global__ __launch_bounds__(512) void k_dn_row(const uint16_t *__restrict__ Xd,
             }
         }
     if (TAIL) {
-#ifdef ORIANA_DN_ABL_RT4
-        rt = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
-#endif
         // lane 4 b + j holds, in register e, the tail sum of cell 4 (b % 8) + e and factor KM + j over its half's genes
         rt.x += __shfl_xor(rt.x, 32, 64); rt.y += __shfl_xor(rt.y, 32, 64);
         rt.z += __shfl_xor(rt.z, 32, 64); rt.w += __shfl_xor(rt.w, 32, 64);

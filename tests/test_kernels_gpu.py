@@ -755,7 +755,7 @@ def test_k100_kernels_shapes(eng, K, m):
     X = (rng.poisson(2.0, size=(n, m)) + 1) * (rng.random((n, m)) < rng.beta(1.0, 2.0, size=m))
     lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
     Zi, Zj, rZi, rZj, ws = _run_gap(eng, X.astype(np.int64), lu, lv)
-    assert eng._lib.load().oriana_col_block_tiles(K) == (1 if os.environ.get('ORIANA_PASS_IMPL') == 'r1' else 2)
+    assert eng._lib.load().oriana_col_block_tiles(K) == 2
     assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
     np.testing.assert_allclose(Zi.sum(1), X.sum(1), rtol=2e-5, atol=1e-3)
     np.testing.assert_allclose(Zj.sum(1), X.sum(0), rtol=2e-5, atol=1e-3)

@@ -25,13 +25,7 @@ def _split_by_default():
 
 def _two_lane_rows(K):
     """Does the row pass of this K run on the two-lane kernels (the only ones that split single row blocks)?"""
-    import os
-    impl = os.environ.get('ORIANA_PASS_IMPL', '')
-    if 85 <= K <= 100:
-        return impl != 'r1'
-    if 33 <= K <= 64:
-        return impl not in ('r1', 'r2', 'r3')
-    return False
+    return 85 <= K <= 100 or 33 <= K <= 64
 
 
 def _counts(rng, n, m, density):
@@ -134,7 +128,7 @@ def test_gene_split_rule(eng):
         pytest.skip('ORIANA_ROW_SPLIT / ORIANA_ROW_SPLITS override the rule')
     rng = np.random.default_rng(1)
     small = eng.CountTiles.from_dense(_counts(rng, 300, 2000, 0.05), 'cuda')       # 2 row blocks x 8 gene tiles
-    assert eng.ZWorkspace(small, 20).row_gene_splits == 8 and eng.ZWorkspace(small, 20).R.shape == (8, 300, 20)
+    assert eng.ZWorkspace(small, 20).row_gene_splits == 8 and eng.ZWorkspace(small, 20).R.shape == (8 * 300, 20)
     one_tile = eng.CountTiles.from_dense(_counts(rng, 300, 200, 0.05), 'cuda')
     assert eng.ZWorkspace(one_tile, 20).row_gene_splits == 1
     import scipy.sparse as sp

@@ -729,6 +729,40 @@ def test_config3_zi_full_size_properties(quirks):
     torch.cuda.empty_cache()
 
 
+def test_config3_zi_transient_after_the_default_nmf_start():
+    """[r5] BASELINE.json configs[2] from the reference's DEFAULT start (use_factors=True: NMF factors as initial shapes,
+    oriana/models/base.py:15, 37-40; gap.py:46-65).  The cells' row maxima of E[log U] spread over 25-45 log units for a dozen
+    sweeps and thousands of tiles hold entries below even the floor of the den threshold: they take the exact slow path.
+    Round 4 evaluated every such entry in ONE thread (2 K expf in sequence, scattered atomics): 8.3 -> 12.3 ms per sweep at the
+    worst (profiles/r04_zigap_slow_path_trace.txt).  Now a wave per entry, lanes over the factors (k_fixup): the transient is
+    bounded -- no sweep after the first (which allocates) above 1.25 x the settled one -- and it IS a transient: slow-path
+    tiles appear and are gone by the end."""
+    from oriana_amd import engine
+    from oriana_amd.models import ZIGaP
+    from oriana_amd.singlecell import SyntheticCounts
+    n, m, K = 100000, 20000, 50
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip('needs ~40 GB of free HBM')
+    gen = SyntheticCounts(n, m, K, seed=77, device='cuda', zero_inflation_level=0.1)
+    ct = engine.CountTiles.from_chunks(n, m, gen.chunk, 8192, 'cuda')
+    model = ZIGaP(ct, k=K, use_factors=True, init='nmf', device='cuda')
+    ev, flagged = [], []
+    for it in range(30):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); model.step(); b.record()
+        ev.append((a, b))
+        flagged.append(int(model._ws.tile_flag[:ct.nrb * ct.ncb].sum().item()))
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    settled = sorted(ms[-5:])[2]
+    assert max(flagged) > 100 and flagged[-1] == 0, flagged
+    assert max(ms[1:]) <= 1.25 * settled, (max(ms[1:]), settled, [round(v, 2) for v in ms], flagged)
+    assert np.isfinite(model.alpha1.asarray()).all() and np.isfinite(model.pi_d.asarray()).all()
+    del model, ct, gen
+    torch.cuda.empty_cache()
+
+
 def test_config3_zi_slab_against_float64_oracle():
     """BASELINE.json configs[2] at full size on the DEFAULT (bf16 x 3) path: after two sweeps, the first 2000 cells of the
     sweep's own loop nest (zigap.py:79-95, the model's D_hat rows and index quirk) against the C oracle, and the rate terms

@@ -190,7 +190,7 @@ def _row_plan(lib, nrb, ncb, K, cus, cost=None):
 def test_row_plan_for_128_256_304_compute_units(lib):
     """The rounds of the chip are rounds of ITS compute units (a literal 256 silently inverts the optimisation on a
     partitioned or differently binned part)."""
-    for v in ('ORIANA_PASS_IMPL', 'ORIANA_ROW_SPLITS', 'ORIANA_ROW_SPLIT_ROUNDS'):
+    for v in ('ORIANA_ROW_SPLITS', 'ORIANA_ROW_SPLIT_ROUNDS'):
         if os.environ.get(v):
             pytest.skip('%s overrides the rule' % v)
     # the headline shape: 3907 row blocks

@@ -835,11 +835,16 @@ static int64_t pick_splits(int64_t blocks, int64_t max_splits) {
 
 // logit(pi_d) in float32, with the overrides of zigap.py:133-134 encoded as -inf (pi_d <= 0: p_d = 1e-10) and +inf
 // (pi_d >= 1: p_d = 1 - 1e-10, 1 in float32)
-__global__ void k_logit_f32(float *__restrict__ lg, const double *__restrict__ pi_d, int64_t m) {
+// [r5] lgs (may be NULL): the same as -logit * log2(e) -- the form dn::k_zi_row takes: its sigmoid is
+// 1 / (1 + exp2(fma(Lambda, log2 e, lgs))), one fused multiply-add where the subtraction and the scaling were two instructions
+// per entry (floating-point vector work beside matrix instructions is the dear kind on this part, DESIGN.md 10 i)
+__global__ void k_logit_f32(float *__restrict__ lg, float *__restrict__ lgs, const double *__restrict__ pi_d, int64_t m) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const double pi = pi_d[j];
-    lg[j] = (pi <= 0.0) ? -INFINITY : (pi >= 1.0) ? INFINITY : (float)logit_f64(pi);
+    const float v = (pi <= 0.0) ? -INFINITY : (pi >= 1.0) ? INFINITY : (float)logit_f64(pi);
+    lg[j] = v;
+    if (lgs) lgs[j] = -v * 1.4426950408889634f;
 }
 
 template <int NT>
@@ -1073,7 +1078,7 @@ extern "C" int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K) {
     // images of csrc/dense_zi.hip for 64 < K <= 100)
     const int64_t a = b16_img_floats(m, 4 * 3 * 64) + b16_img_floats(m, 2 * 2 * 3 * 64);
     const int64_t b = (K > 32 && K <= 100) ? dn::zi_sweep_image_floats(m) : 0;
-    return (m + 63) / 64 * 64 + (a > b ? a : b);
+    return 2 * ((m + 63) / 64 * 64) + (a > b ? a : b);       // logits, scaled logits (dense_zi.hip), images
 }
 
 extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d64,
@@ -1086,15 +1091,17 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
     if (((uintptr_t)scratch & 15) != 0) return ORIANA_EINVAL;
     if (arithmetic != ORIANA_MATRIX_F32 && arithmetic != ORIANA_MATRIX_BF16X3) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, pi_d64, m);
+    const int64_t mpad = (m + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, scratch + mpad, pi_d64, m);
     const float *pi_d = scratch;
+    scratch += mpad;                                   // (the scaled logits; the operand images follow them)
     int rc = ORIANA_EKRANGE;
     if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K))
-        rc = dn::zi_sweep(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, scratch + (m + 63) / 64 * 64, n, m, (int)K, st);
+        rc = dn::zi_sweep(D_hat, U, V, scratch, nzmask, colsum, V_next, DV_next, scratch + mpad, n, m, (int)K, st);
     if (rc != ORIANA_EKRANGE) {
         // (done, or failed for good; ORIANA_EKRANGE = not this kernel's case, e.g. a D_hat that is not 16-byte aligned)
     } else if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
-        float *img = scratch + (m + 63) / 64 * 64;
+        float *img = scratch + mpad;
         switch ((int)((K + 15) / 16)) {
             case 1: rc = launch_sweep_b16<1, 1>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;
             case 2: rc = launch_sweep_b16<1, 2>(D_hat, U, V, pi_d, nzmask, colsum, V_next, DV_next, img, n, m, (int)K, st); break;

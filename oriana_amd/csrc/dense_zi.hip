@@ -289,10 +289,10 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                         lg4 = __builtin_bit_cast(f4v, im0[MP + 64 + 2 * q + h]);
                         mk4 = im0[MP + w * 8 + 2 * q + h];
                     }
-                    const float lg = lg4[v & 3];
-                    const float x = lg - l0[v];
-                    float p = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-                    p = (lg == -INFINITY) ? 1e-10f : p;                   // pi_d <= 0                        zigap.py:133
+                    // lgs = -logit(pi_d) log2(e) (k_logit_f32): sigmoid(logit - Lambda) = 1 / (1 + exp2(Lambda log2(e) + lgs))
+                    const float lgs = lg4[v & 3];
+                    float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(l0[v], 1.4426950408889634f, lgs)));
+                    p = (lgs == INFINITY) ? 1e-10f : p;                   // pi_d <= 0 (lgs = +inf)           zigap.py:133
                     p = ((mk4[v & 3] >> c) & 1u) ? 1.0f : p;              // X != 0: f32(1 - 1e-10) == 1      zigap.py:135
                     l0[v] = p;
                     if ((v & 3) == 3) *reinterpret_cast<f4v *>(Tw + 8 * q) = f4v{l0[v - 3], l0[v - 2], l0[v - 1], l0[v]};
@@ -587,11 +587,8 @@ static int64_t zi_pick_splits(int64_t blocks, int64_t max_splits) {
 // Smallest K served here: 33.  Measured at 100k x 20k against dense_f32.hip's bf16 kernels (tools/perf_zi_per_k.py): D update
 // 3.45 against 4.11 ms at K = 48, 3.82 against 4.00 ms at K = 50; D^T U 1.82 against 2.00 ms at K = 48 but 2.06 against
 // 1.98 ms at K = 50 (the tail factors' 4 x 4 x 1 instructions): below 65 the transposed product comes here only when Kp has
-// no tail.  ORIANA_ZI_DN_MINK raises the limit for A/B measurements (65: round 2's assignment).
-static int64_t zi_min_k() {
-    static const int64_t v = [] { const char *e = getenv("ORIANA_ZI_DN_MINK"); const long x = e ? atol(e) : 33; return (int64_t)(x < 33 ? 33 : x); }();
-    return v;
-}
+// no tail.
+static int64_t zi_min_k() { return 33; }
 
 static bool zi_cfg(int64_t K, int *kc, int *tl) {
     const int64_t Kp = oriana_kpad(K);
@@ -614,7 +611,7 @@ bool zi_dt_supported(int64_t m, int64_t K) {                               // D_
 int64_t zi_sweep_image_floats(int64_t m) { return ((m + 31) / 32) * (int64_t)Cfg<6, 1>::PV * 4; }
 int64_t zi_dt_image_floats(int64_t n) { return ((n + 31) / 32 + 2) * (int64_t)Cfg<6, 1>::PU * 4; }
 
-int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, const uint32_t *nzmask, double *colsum,
+int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit /* scaled: -logit log2(e) */, const uint32_t *nzmask, double *colsum,
              const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m, int K, hipStream_t st) {
     int kc, tl;
     if (!zi_cfg(K, &kc, &tl) || (m % 4) != 0 || m > 16000000 || !Vn || !DV || !nzmask) return ORIANA_EKRANGE;

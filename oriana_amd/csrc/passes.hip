@@ -487,16 +487,12 @@ extern "C" int oriana_row_pass_plan_cus(const oriana_counts *cm, int64_t K, cons
     if (!pick_cfg(K, &cfg) || cm->nrb <= 0 || cm->ncb <= 1) return 0;
     const bool two_lane = use_k100(cfg.G, cfg.T4) || (k64_kernels() && k64_cfg(cfg.G, cfg.T4, cfg.TAIL));
     const int64_t groups = cm->nrb * ((two_lane || use_narrow(cfg.G, cfg.T4, cfg.TAIL)) ? 1 : (TILE / (16 * (64 / cfg.G))));
-    static const int forced = [] { const char *e = getenv("ORIANA_ROW_SPLITS"); return e ? atoi(e) : 0; }();   // tuning runs
-    static const bool rounds_off = [] { const char *e = getenv("ORIANA_ROW_SPLIT_ROUNDS"); return e && !strcmp(e, "off"); }();
     int64_t nfull = 0, parts = 1;
-    if (forced > 0) {
-        parts = forced;
-    } else if (groups < cus) {
+    if (groups < cus) {
         // short matrices: two work-groups per CU at most, evenly sized ranges (measured at 10,000 x 2,000, K = 20:
         // 77 / 42 / 25 / 24 us for 1 / 2 / 4 / 8 groups per row block; 8 is the better sweep)
         parts = 2 * cus / groups;
-    } else if (two_lane && !rounds_off) {
+    } else if (two_lane) {
         // One 512-thread group per CU (the image and the registers leave room for one): the pass advances in rounds of `cus`
         // (256 on the MI355X the figures are from) row blocks and a partly filled last round costs a whole one (1M x 30k, K = 100: 3840 / 3907 / 4096 row blocks =
         // 33.9 / 35.8 / 36.2 ms; 391 row blocks -- configs[2] -- run as two rounds).  The row blocks of the last round are
@@ -650,23 +646,8 @@ static int launch_col_pass_dual(const oriana_counts *cm, const float *s_cs, cons
                                 float *C2, const int32_t *work, int64_t nwork, hipStream_t s) {
     constexpr int T4c = (G == 4) ? T4 : 1, TLc = (G == 4) ? TAIL : 0;
     using Im = ColImage<T4c, TLc>;
-    if constexpr (k64_cfg(G, T4, TAIL)) {
-        // measured at configs[4] (500k x 25k, K = 64): 11.3 ms against 10.9 ms for the four-lane kernel below -- with two
-        // images per step the walk is bound by the LDS return port either way; ORIANA_COL_DUAL=k64 selects it for A/B runs
-        static const bool dual64 = [] { const char *e = getenv("ORIANA_COL_DUAL"); return e && e[0] == 'k'; }();
-        if (k64_kernels() && dual64) {
-            if (nwork <= 0) return 0;
-            constexpr int KP4 = 4 * T4 + TAIL;
-            const size_t lb6 = (size_t)k64::IMG4 * 16 * 2;
-            auto kern6 = k64::k_col_pass_k64<KP4, true>;
-            int rc6 = set_lds(kern6, lb6);
-            if (rc6) return rc6;
-            hipLaunchKernelGGL(kern6, dim3((unsigned)nwork), dim3(1024), lb6, s, *cm, s_cs, G1, C1, work, (int64_t)0,
-                               (float *)nullptr, G2, C2);
-            ORIANA_LAUNCH_CHECK();
-            return 0;
-        }
-    }
+    // (33 <= Kp <= 64: the two-lane dual kernel k64::k_col_pass_k64<KP4, true> measured 11.3 ms against 10.9 ms for this four-lane
+    //  one at configs[4] -- with two images per step the walk is bound by the LDS return port either way; it is not dispatched)
     if (G != 4 || Im::DUP || 2 * Im::bytes() > (size_t)LDS_BUDGET) return ORIANA_EKRANGE;
     if (nwork <= 0) return 0;
     constexpr bool OK = (G == 4) && !Im::DUP;

@@ -457,8 +457,6 @@ static int launch_map(double *y, const double *x, int64_t len, void *stream) {
 // per block the gene side (30,000 rows) ran on 59 of the 256 CUs and one rank's share of the cell side
 // (125,000 rows) on 245, a single 4-wave block each: 0.34 ms per call instead of ~0.1.
 static inline int rows_per_block(int64_t r, int ry) {
-    static const int forced = [] { const char *e = getenv("ORIANA_GU_RPB"); return e ? atoi(e) : 0; }();   // tuning runs
-    if (forced > 0) return (forced + ry - 1) / ry * ry;
     int64_t rpb = (r + 2047) / 2048;
     rpb = (rpb + ry - 1) / ry * ry;
     if (rpb < 4 * ry) rpb = 4 * ry;
@@ -474,8 +472,6 @@ static inline void pick_block(int64_t K, dim3 *block, int threads = 256) {
 
 // short matrices: 1024-thread groups, four rows per thread (see k_gamma_update)
 static inline bool gu_large_groups(int64_t r) {
-    static const int forced = [] { const char *e = getenv("ORIANA_GU_THREADS"); return e ? atoi(e) : 0; }();   // tuning runs
-    if (forced) return forced == 1024;
     // (inside a configs[1] sweep: 10,000 rows 19.3 us with 1024-thread groups against 22.4 with 256; 2,000 rows 13.8 against 9.6)
     return r > 4096 && r <= 32768;
 }

@@ -177,11 +177,10 @@ class CountTiles:
         cap = int(lib.oriana_plan_col_work_capacity(self.nrb, self.ncb, int(width)))
         items = np.empty((max(cap, 1), 3), dtype=np.int32)
         n_items = ctypes.c_int64(0)
-        # (the pair's price: the maximum of the two slices; with the constants fitted to it the sum measured 2.6 % slower on
-        #  the column pass at C4, ORIANA_COL_PRICE=sum.  ORIANA_COL_ROUNDS=off: the first cut, not re-cut to whole rounds)
+        # (the pair's price: the maximum of the two slices -- with the constants fitted to it the sum measured 2.6 % slower on
+        #  the column pass at C4, DESIGN.md 10 j; re-cut to whole rounds of the chip, DESIGN.md 10 l)
         call('oriana_plan_col_work', nit.ctypes.data, self.nrb, self.ncb, int(width), int(lib.oriana_device_cus()),
-             int(target_items or 0), 0 if os.environ.get('ORIANA_COL_ROUNDS', 'on') == 'off' else 1,
-             1 if os.environ.get('ORIANA_COL_PRICE') == 'sum' else 0, items.ctypes.data, cap, ctypes.addressof(n_items))
+             int(target_items or 0), 1, 0, items.ctypes.data, cap, ctypes.addressof(n_items))
         return torch.from_numpy(items[:int(n_items.value)].copy()).to(self.device).contiguous()
 
     def col_work_for(self, K):
@@ -200,7 +199,7 @@ class CountTiles:
         self.gene_tile_cost = None
         if self.tile_rslots is not None and self.nrb * self.ncb > 0:
             per = self.tile_rslots[:self.nrb * self.ncb].view(self.nrb, self.ncb).to(torch.float64).mean(dim=0) / (16 * 64)
-            stage = float(os.environ.get('ORIANA_TILE_STAGE_COST', '2.0'))        # (tuning runs)
+            stage = 2.0                      # (staging a tile's 256 factor rows, in slice iterations: flat between 0.5 and 4, DESIGN.md 10 l)
             self.gene_tile_cost = np.ascontiguousarray((per + stage).cpu().numpy(), dtype=np.float64)
         self.tile_rslots = self.tile_cslots = None
         if self.gd and self.col_perm is None:
@@ -520,8 +519,6 @@ class ZWorkspace:
             gsp, csp = ctypes.c_int64(1), ctypes.c_int64(1)
             call('oriana_plan_dense_splits', ct.n, d.gd, int(lib.oriana_device_cus()), ctypes.addressof(gsp), ctypes.addressof(csp))
             self.dn_gene_splits, self.dn_cell_splits = int(gsp.value), int(csp.value)
-            if os.environ.get('ORIANA_DN_GENE_SPLITS'):                     # tuning runs
-                self.dn_gene_splits = max(1, min(d.ngt, int(os.environ['ORIANA_DN_GENE_SPLITS'])))
 
     def _alloc_R(self, parts, row0):
         """The row sums: slab 0 for every row; slabs 1 .. parts - 1 for the rows from `row0` on only (the row blocks of the
@@ -535,8 +532,7 @@ class ZWorkspace:
         """(first split 256-cell block, parts) of the dense row kernel: the split of the sliced row pass's last round when the
         row sums of this call have that many slabs (and the dense kernel no split of its own), else no split."""
         sp = self.row_split
-        if sp.nfull > 0 and 1 < sp.parts == nslab and self.dn_gene_splits == 1 and sp.parts <= self.ct.dense.ngt \
-                and os.environ.get('ORIANA_DN_TAIL', 'on') != 'off':
+        if sp.nfull > 0 and 1 < sp.parts == nslab and self.dn_gene_splits == 1 and sp.parts <= self.ct.dense.ngt:
             return int(sp.nfull), int(sp.parts)
         return 0, 1
 
@@ -820,9 +816,9 @@ def zq_gap_stateless(Z_hat_i, Z_hat_j, log_U_hat, log_V_hat, X):
          base, nbytes, stream_ptr())
 
 
-# ORIANA_SPARSE_ROWS=split keeps the two-kernel form of the sparse row phase (A/B runs)
-_FUSE_SPARSE_ROWS = os.environ.get('ORIANA_SPARSE_ROWS', 'fused') != 'split'
-_FUSE_SPARSE_COLS = os.environ.get('ORIANA_SPARSE_COLS', 'fused') != 'split'
+# (module switches for tests: the two-kernel forms of the sparse row / column phase, which every Kp > 64 takes anyway)
+_FUSE_SPARSE_ROWS = True
+_FUSE_SPARSE_COLS = True
 
 
 def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=None, w_nz=None, phase='all'):

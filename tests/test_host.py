@@ -206,9 +206,6 @@ def test_row_pass_plan_rounds_of_the_chip(monkeypatch):
     """oriana_row_pass_plan is host arithmetic (no GPU): the two-lane kernels (one work-group per CU) keep the row blocks of
     the full rounds of 256 whole and cut those of the last round into gene ranges of equal cost; short matrices split every
     row block; the other kernels and full last rounds do not split."""
-    for v in ('ORIANA_ROW_SPLITS', 'ORIANA_ROW_SPLIT_ROUNDS'):
-        if os.environ.get(v):
-            pytest.skip('%s overrides the rule' % v)
     # the headline: 3907 row blocks = 15 rounds + 67 row blocks, in three ranges (201 work-groups: one third of a round)
     nfull, parts, edges = _plan(3907, 118, 100)
     assert (nfull, parts, edges) == (3840, 3, [0, 39, 79, 118])

@@ -20,7 +20,7 @@ def eng():
 
 def _split_by_default():
     import os
-    return os.environ.get('ORIANA_ROW_SPLIT', 'auto') != 'off' and not os.environ.get('ORIANA_ROW_SPLITS')
+    return os.environ.get('ORIANA_ROW_SPLIT', 'auto') != 'off'
 
 
 def _two_lane_rows(K):
@@ -125,7 +125,7 @@ def test_row_pass_gene_split_matches_one_group_per_row_block(eng, K):
 def test_gene_split_rule(eng):
     """1 from 256 row-side work-groups on; otherwise enough groups for two per CU, at most one per gene tile."""
     if not _split_by_default():
-        pytest.skip('ORIANA_ROW_SPLIT / ORIANA_ROW_SPLITS override the rule')
+        pytest.skip('ORIANA_ROW_SPLIT=off overrides the rule')
     rng = np.random.default_rng(1)
     small = eng.CountTiles.from_dense(_counts(rng, 300, 2000, 0.05), 'cuda')       # 2 row blocks x 8 gene tiles
     assert eng.ZWorkspace(small, 20).row_gene_splits == 8 and eng.ZWorkspace(small, 20).R.shape == (8 * 300, 20)
@@ -137,7 +137,7 @@ def test_gene_split_rule(eng):
     # [r4] the one-group-per-CU kernels (33 <= Kp <= 64, 85 <= K <= 100) split the row blocks of a partly filled LAST round of
     # the chip: 391 row blocks = 256 whole + 135 in five gene ranges (3 / 5 of a round); 489 = 256 + 233: two rounds anyway
     import os
-    if os.environ.get('ORIANA_ROW_SPLIT_ROUNDS') != 'off':
+    if True:
         c3 = eng.CountTiles.from_scipy(sp.random(100000, 1200, density=0.004, format='csr', random_state=3, dtype=np.float32), 'cuda')
         assert c3.nrb == 391 and c3.ncb == 5
         for K in (50, 100):                                                      # the 135 row blocks of the second round in 5 ranges
@@ -236,7 +236,7 @@ def test_hybrid_layout_with_a_split_last_round(eng, K, nest):
             continue
         got, tail = run(split)
         # (what a call with that many slabs hands the dense kernel; the unfused sparse form, K > 64, has one slab and no dense split)
-        assert tail == ((split[0], split[1]) if os.environ.get('ORIANA_DN_TAIL', 'on') != 'off' else (0, 1))
+        assert tail == (split[0], split[1])
         for a, b in zip(got, ref):
             sc = b.abs().max(0, keepdim=True).values.clamp_min(1e-30)
             assert float(((a - b).abs() / (b.abs() + sc)).max()) < 3e-6, (split, nest)

@@ -943,7 +943,7 @@ def test_sparse_zi_at_config3_shape_against_float64_kernels():
     a1, b1 = gen.initial_shapes()
     fast = SparseZIGaP(ct, k=K, init=(a1, b1), device='cuda')
     if not (fast._fast_dense and engine._FUSE_SPARSE_ROWS and engine._FUSE_SPARSE_COLS):
-        pytest.skip('a switch (ORIANA_ZI_EXACT / ORIANA_SPARSE_ROWS / ORIANA_SPARSE_COLS) turns the compared path off')
+        pytest.skip('a switch (ORIANA_ZI_EXACT) turns the compared path off')
     fast.fit(3)
     assert fast.n_kept_products == 2 and fast._ws.s_rs is None
     fused = (engine._FUSE_SPARSE_ROWS, engine._FUSE_SPARSE_COLS)

@@ -190,9 +190,6 @@ def _row_plan(lib, nrb, ncb, K, cus, cost=None):
 def test_row_plan_for_128_256_304_compute_units(lib):
     """The rounds of the chip are rounds of ITS compute units (a literal 256 silently inverts the optimisation on a
     partitioned or differently binned part)."""
-    for v in ('ORIANA_ROW_SPLITS', 'ORIANA_ROW_SPLIT_ROUNDS'):
-        if os.environ.get(v):
-            pytest.skip('%s overrides the rule' % v)
     # the headline shape: 3907 row blocks
     assert _row_plan(lib, 3907, 118, 100, 256) == (3840, 3, [0, 39, 79, 118])
     nfull, parts, _ = _row_plan(lib, 3907, 118, 100, 128)          # 30 rounds of 128 + 67: 67 x 2 = 134 -> 2 rounds / 2 ...

@@ -753,6 +753,7 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
                      'dense_arithmetic': 'float64' if not model._fast_dense else ('bf16x3' if model._matrix_arith == 1 and K <= 64 else 'f32 matrix instruction')}
         else:
             nest = 'sparse_gap.py:81-97 (S_tilde, S_hat of the model)'
+            model._threshold()                       # S_tilde = p_s > tau as the NEXT sweep will take it (sparse_gap.py:113; idempotent)
             St = np.ascontiguousarray(model._S_tilde.cpu().numpy())
             Sh = np.ascontiguousarray(model._S_hat.cpu().numpy())
             co.zq_sparse_gap(Zi_o, Zj_o, Zl_o, lus, lvs, St, Sh, Xs)
@@ -785,6 +786,29 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
             slab['Z_log'] = colrel(Zl_h.cpu().numpy(), Zl_o.astype(np.float64))
             slab['Z_log_strict'] = strictrel(Zl_h.cpu().numpy(), Zl_o.astype(np.float64))
         slab.update(extra)
+        # ---- [r5] one SWEEP on the slab's cells: the model takes its next step() from the very state the oracle nest above was
+        # evaluated on, and the cell-side update of those rows (gap.py:96-102 / zigap.py:114-120 / sparse_gap.py:117-124:
+        # a1 = alpha1 + Z_i, a2 = alpha2 + rate, then Gamma.mean / Gamma.meanlog) is restated from the ORACLE's Z_i
+        try:
+            al1 = model.alpha1.tensor.cpu().numpy().copy(); al2 = model.alpha2.tensor.cpu().numpy().copy()
+            if mname == 'GaP':
+                rate = model._V_hat.sum(0).cpu().numpy()[None, :]
+            elif mname == 'SparseGaP':
+                rate = (model._S_hat.double() * model._V_hat).sum(0).cpu().numpy()[None, :]
+            else:
+                rate = DV_ref
+            model.step()
+            torch.cuda.synchronize()
+            a1_ref = co.clamp(al1[None, :] + Zi_o)
+            a2_ref = co.clamp(np.broadcast_to(al2[None, :] + rate, a1_ref.shape).copy())
+            got = {'a1': model.a1.tensor[:srows].cpu().numpy(), 'a2': model.a2.tensor[:srows].cpu().numpy(),
+                   'U_hat': model._U_hat[:srows].cpu().numpy(), 'log_U_hat': model._log_U_hat[:srows].cpu().numpy()}
+            ref = {'a1': a1_ref, 'a2': a2_ref, 'U_hat': co.gamma_mean(a1_ref, a2_ref), 'log_U_hat': co.gamma_meanlog(a1_ref, a2_ref)}
+            slab['sweep_cell_side'] = {k: colrel(got[k], np.asarray(ref[k], dtype=np.float64)) for k in got}
+            slab['sweep_cell_side']['what'] = ('model.step() from that state: a1, a2, U_hat, log_U_hat of the slab\'s cells after the sweep '
+                                               'against the update restated from the oracle\'s Z_i (column metric)')
+        except Exception as e2:
+            slab['sweep_cell_side'] = {'error': repr(e2)[:200]}
     except Exception as e:
         import traceback
         slab = {'error': repr(e), 'trace': traceback.format_exc()[-600:]}

@@ -525,6 +525,12 @@ static bool gu_vec_launch(GuVecArgs a, hipStream_t s) {
     return true;
 }
 
+// Short matrices are latency-bound (a sweep of configs[1] is a dozen launches of microseconds): there a thread's serial
+// chain is what counts, and one element per lane (k_gamma_update, large groups) is the shorter one -- measured at 2,000 x 20:
+// 10.3 us against 15.0 us, at 10,000 x 20: 15.7 against 17.4 (profiles/r05_perf_gamma*.txt).  The vector kernel takes over from
+// 2^20 elements on (30,000 x 100: 46 against 60 us), and whenever its PREP outputs are asked for.
+static inline bool gu_small(int64_t r, int64_t K) { return r * K < (int64_t)1 << 20; }
+
 static inline bool gu_scalar_forced() {
     static const bool f = [] { const char *e = getenv("ORIANA_GU_KERNEL"); return e && !strcmp(e, "r4"); }();   // A/B runs
     return f;
@@ -552,7 +558,7 @@ extern "C" int oriana_gamma_update_prep(double *a1, double *a2, double *E, float
     if (!a1 || !a2 || !E || !Elog) return ORIANA_EINVAL;
     if (Z && (!prior1 || !prior2 || (!rate_vec && !rate_mat))) return ORIANA_EINVAL;
     if (FU_next && (!mu_out || !upart || oriana_kpad(K) == 0)) return ORIANA_EINVAL;
-    if (!gu_scalar_forced()) {
+    if (!gu_scalar_forced() && (FU_next || !gu_small(r, K))) {
         GuVecArgs a = {a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, 0,
                        nullptr, nullptr, nullptr, nullptr, (int)oriana_kpad(K), 1, 0, FU_next, mu_out, upart};
         if (gu_vec_launch<false>(a, (hipStream_t)stream)) { ORIANA_LAUNCH_CHECK(); return 0; }
@@ -594,7 +600,7 @@ extern "C" int oriana_gamma_update_finalize_prep(double *a1, double *a2, double 
     if (r == 0) return 0;
     if (!a1 || !a2 || !E || !Elog || !Z || !F || !R || !prior1 || !prior2 || !rate_vec) return ORIANA_EINVAL;
     if (FU_next && (!mu_out || !upart)) return ORIANA_EINVAL;
-    if (!gu_scalar_forced()) {
+    if (!gu_scalar_forced() && (FU_next || !gu_small(r, K))) {
         GuVecArgs a = {a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, nullptr, nullptr, rate_vec, nullptr, nullptr, r, (int)K, 0,
                        Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0, FU_next, mu_out, upart};
         if (gu_vec_launch<true>(a, (hipStream_t)stream)) { ORIANA_LAUNCH_CHECK(); return 0; }

@@ -485,7 +485,9 @@ class ZWorkspace:
         # (oriana_gamma_update_prep): FU in a second buffer (the gene-side kernels of the running sweep still read the
         # current one), the row maxima, the per-group partial statistics.  fu_pending: they describe the E[log U] at hand.
         self.prep_blocks = int(_lib.load().oriana_gamma_update_prep_blocks(max(ct.n, 0), int(K))) if ct.n > 0 else 0
-        if os.environ.get('ORIANA_FUSED_PREP', 'on') == 'off':          # A/B runs
+        # (not for short matrices: below 2^20 elements the sweep is launch-bound and the one-element-per-lane Gamma kernel
+        #  is the faster one, csrc/updates.hip gu_small; ORIANA_FUSED_PREP=off: A/B runs)
+        if os.environ.get('ORIANA_FUSED_PREP', 'on') == 'off' or (os.environ.get('ORIANA_FUSED_PREP') != 'force' and ct.n * int(K) < (1 << 20)):
             self.prep_blocks = 0
         self.FU_alt = self.mu_u = self.upart = None
         self.fu_pending = False

@@ -129,18 +129,18 @@ def test_models_with_and_without_the_fused_preparation(eng, model_name, K, monke
     states = {}
     eng.set_deterministic(True)
     try:
-        for mode in ('on', 'off'):
+        for mode in ('force', 'off'):                  # (force: also below the 2^20 elements from which 'on' takes it)
             monkeypatch.setenv('ORIANA_FUSED_PREP', mode)
             mdl = cls(X, k=K, init=(a1, b1), dense_density=None)
-            assert (mdl._ws.prep_blocks > 0) == (mode == 'on')
+            assert (mdl._ws.prep_blocks > 0) == (mode == 'force')
             for _ in range(4):
                 mdl.step()
-            if mode == 'on':
+            if mode == 'force':
                 assert mdl._ws.fu_pending and mdl._ws.FU_alt is not None
             states[mode] = mdl.state()
     finally:
         eng.set_deterministic(False)
-    for k, v in states['on'].items():
+    for k, v in states['force'].items():
         ref = states['off'][k]
         if v.dtype.kind == 'f':
             scale = np.abs(ref).max(axis=0, keepdims=True) if ref.ndim == 2 else np.abs(ref).max()
@@ -148,13 +148,14 @@ def test_models_with_and_without_the_fused_preparation(eng, model_name, K, monke
             assert float(np.nanmax(err)) <= 2e-6, (k, float(np.nanmax(err)))
 
 
-def test_a_foreign_log_matrix_does_not_take_the_pending_preparation(eng):
+def test_a_foreign_log_matrix_does_not_take_the_pending_preparation(eng, monkeypatch):
     """engine.zq_gap on the model's workspace with ANOTHER E[log U] (bench.py's parity slab, tests) must prepare from that
     matrix, not from what the last sweep left."""
     from oriana_amd import models
     rng = np.random.default_rng(6)
     n, m, K = 600, 300, 20
     X = _counts(rng, n, m, 0.2)
+    monkeypatch.setenv('ORIANA_FUSED_PREP', 'force')
     mdl = models.GaP(X, k=K, init=(rng.gamma(1.0, size=(n, K)) + 0.1, rng.gamma(1.0, size=(m, K)) + 0.1), dense_density=None)
     mdl.step()
     ws = mdl._ws

@@ -187,3 +187,58 @@ def test_resident_argument_errors(lib):
     Zi2, Zj2, l1, l2 = torch.empty(300, 20, device='cuda'), torch.empty(64, 20, device='cuda'), torch.zeros(300, 20, device='cuda'), torch.zeros(64, 20, device='cuda')
     assert lib.oriana_zq_zigap_resident(hh, ptr(Zi2), ptr(Zj2), ptr(Zl), ptr(l1), ptr(l2), ptr(D), 0, stream_ptr()) == -1
     lib.oriana_counts_destroy(hh)
+
+
+def test_resident_edge_shapes_and_ineligible_genes(lib):
+    """Ragged shapes (one cell, one gene, n and m off every tile boundary), K = 1, genes whose counts do not fit the uint16 block
+    (>= 65535, non-integer: they stay on the sliced layout of a hybrid handle), CSR with duplicate entries and empty rows."""
+    from oracle import cavi_oracle as co
+    from oriana_amd._lib import ptr, stream_ptr
+    import scipy.sparse as sp
+    rng = np.random.default_rng(42)
+    for n, m, K, dd in ((1, 1, 1, 0.0), (1, 300, 3, 0.0), (257, 1, 2, 0.0), (33, 65, 5, 0.5), (513, 259, 20, 0.3)):
+        X = (rng.poisson(2.0, size=(n, m)) * (rng.random((n, m)) < 0.6)).astype(np.float32)
+        if m > 40:
+            X[:, 3] = 70000.0                       # too large for the uint16 block
+            X[0, 7] = 2.5                            # not an integer
+        lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+        h = _create(lib, X, K, dd)
+        info = _info(lib, h)
+        assert info[4] == int(np.count_nonzero(X))
+        if dd > 0 and m > 40:
+            assert info[5] % 32 == 0 and info[5] <= int(((X != 0).mean(0) >= dd).sum())
+        Zi, Zj = torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda')
+        assert lib.oriana_zq_gap_resident(h, ptr(Zi), ptr(Zj), ptr(torch.from_numpy(lu).cuda()), ptr(torch.from_numpy(lv).cuda()), stream_ptr()) == 0
+        torch.cuda.synchronize()
+        rZi = np.empty((n, K), np.float32); rZj = np.empty((m, K), np.float32)
+        co.zq_gap(rZi, rZj, lu, lv, X)
+        assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5 and err_colrel(Zj.cpu().numpy(), rZj) < 1e-5, (n, m, K, dd)
+        lib.oriana_counts_destroy(h)
+    # CSR: duplicates add up, empty rows, an out-of-range gene index is an argument error
+    n, m, K = 300, 90, 7
+    rows = rng.integers(0, n, size=4000); cols = rng.integers(0, m, size=4000)
+    rows[rows % 11 == 0] = 5                                      # many duplicates, and rows that stay empty
+    vals = rng.integers(1, 6, size=4000).astype(np.float32)
+    order = np.argsort(rows, kind='stable')
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(indptr, rows + 1, 1)
+    indptr = np.cumsum(indptr)
+    X = np.zeros((n, m), dtype=np.float32)
+    np.add.at(X, (rows, cols), vals)
+    assert np.array_equal(sp.csr_matrix((vals, cols, indptr), shape=(n, m)).toarray(), X)
+    indices = np.ascontiguousarray(cols.astype(np.int32)); data = np.ascontiguousarray(vals)
+    h = ctypes.c_void_p(None)
+    assert lib.oriana_counts_create_csr(ctypes.addressof(h), indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n, m, K, 0.0, stream_ptr()) == 0
+    assert _info(lib, h)[4] == int(np.count_nonzero(X))
+    lu = rng.normal(size=(n, K)).astype(np.float32); lv = rng.normal(size=(m, K)).astype(np.float32)
+    Zi, Zj = torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda')
+    assert lib.oriana_zq_gap_resident(h, ptr(Zi), ptr(Zj), ptr(torch.from_numpy(lu).cuda()), ptr(torch.from_numpy(lv).cuda()), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    rZi = np.empty((n, K), np.float32); rZj = np.empty((m, K), np.float32)
+    co.zq_gap(rZi, rZj, lu, lv, X)
+    assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5 and err_colrel(Zj.cpu().numpy(), rZj) < 1e-5
+    lib.oriana_counts_destroy(h)
+    bad = indices.copy(); bad[10] = m
+    h2 = ctypes.c_void_p(None)
+    assert lib.oriana_counts_create_csr(ctypes.addressof(h2), indptr.ctypes.data, bad.ctypes.data, data.ctypes.data, n, m, K, 0.0, stream_ptr()) == -1

@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void k_col_stats(const float *__restrict__ X, 
 __global__ __launch_bounds__(256) void k_gather_cols(float *__restrict__ out, const float *__restrict__ X,
                                                      const int32_t *__restrict__ perm, int64_t rows, int64_t m, int64_t ldx) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t r = blockIdx.y;
-    if (c >= m || r >= rows) return;
-    out[r * m + c] = X[r * ldx + (perm ? perm[c] : (int32_t)c)];
+    if (c >= m) return;
+    const int64_t src = perm ? (int64_t)perm[c] : c;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) out[r * m + c] = X[r * ldx + src];     // (gridDim.y <= 65535)
 }
 
 // rows [r0, r0 + rows) of a CSR matrix into a zeroed dense chunk: one work-group per row
@@ -435,7 +435,8 @@ int resident_build(oriana_resident *h, ChunkSource &src, double dense_density, h
     auto permuted = [&](int64_t r0, int64_t rows) -> int {
         const float *Xc; int64_t ld;
         RES_TRY(src.get(r0, rows, &Xc, &ld, s));
-        hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((m + 255) / 256), (unsigned)rows), dim3(256), 0, s, perm_buf, Xc, h->col_perm, rows, m, ld);
+        hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((m + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, s, perm_buf, Xc,
+                           h->col_perm, rows, m, ld);
         ORIANA_LAUNCH_CHECK();
         return 0;
     };

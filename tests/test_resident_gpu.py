@@ -196,7 +196,8 @@ def test_resident_edge_shapes_and_ineligible_genes(lib):
     from oriana_amd._lib import ptr, stream_ptr
     import scipy.sparse as sp
     rng = np.random.default_rng(42)
-    for n, m, K, dd in ((1, 1, 1, 0.0), (1, 300, 3, 0.0), (257, 1, 2, 0.0), (33, 65, 5, 0.5), (513, 259, 20, 0.3)):
+    # (70,001 cells x 40 genes: more rows in one packing chunk than a grid's y dimension holds)
+    for n, m, K, dd in ((1, 1, 1, 0.0), (1, 300, 3, 0.0), (257, 1, 2, 0.0), (33, 65, 5, 0.5), (513, 259, 20, 0.3), (70001, 40, 4, 0.0)):
         X = (rng.poisson(2.0, size=(n, m)) * (rng.random((n, m)) < 0.6)).astype(np.float32)
         if m > 40:
             X[:, 3] = 70000.0                       # too large for the uint16 block

@@ -556,7 +556,7 @@ def recorded_traffic(workload, world, hybrid=False):
     if world != 1:
         return None, None
     tag = workload + ('_hybrid' if hybrid else '')
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_hbm_%s.json' % (rnd, tag))
         if os.path.exists(path):
             try:

@@ -229,3 +229,23 @@ def test_row_pass_plan_rounds_of_the_chip(monkeypatch):
     assert _plan(40, 8, 20)[:2] == (0, 8)
     # one gene tile: nothing to split
     assert _plan(40, 1, 100)[:2] == (40, 1)
+
+
+def test_bench_secondaries_cannot_cost_the_headline(monkeypatch):
+    """the secondary workloads of the default bench line run in child processes under a wall-clock budget; a
+    child that fails (here: no GPU in the build container) or a spent budget becomes an {'error': ...} entry, never an
+    exception in the process that holds the measured headline."""
+    import importlib.util
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a host without a GPU (the child must fail)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv('ORIANA_BENCH_SECONDARY_BUDGET_S', '120')
+    res = bench.run_secondaries(('c3_zi',))
+    assert len(res) == 1 and res[0]['workload'] == 'c3_zi' and res[0]['error'].startswith('rc=')
+    monkeypatch.setenv('ORIANA_BENCH_SECONDARY_BUDGET_S', '5')
+    res = bench.run_secondaries(('c3_zi', 'c5_sparse'))
+    assert [r['workload'] for r in res] == ['c3_zi', 'c5_sparse'] and all('skipped' in r['error'] for r in res)

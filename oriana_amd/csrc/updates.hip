@@ -75,13 +75,8 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
                     s1 = a1[idx];
                     s2 = a2[idx];
                 }
-#ifdef ORIANA_GU_ABL_NOSPECIAL                                      /* analysis build: the memory side of the kernel alone */
-                const double e = s1 * s2;
-                const float el = (float)s1 - (float)s2;
-#else
                 const double e = s1 / s2;                                // gamma.py:37-46
                 const float el = gamma_meanlog_f32(s1, s2);              // gamma.py:52-61
-#endif
                 E[idx] = e;
                 Elog[idx] = el;
                 sE[c] += e;
@@ -114,12 +109,8 @@ __global__ __launch_bounds__(NT) void k_gamma_update(double *__restrict__ a1, do
                 // KT = 128: rows of threads span two waves; wave 2y + (tx >> 6) holds columns (tx & 63) of row y
                 for (int w = (tx >> 6); w < NW; w += 2) { tE += red[0][w * kw + (tx & 63)]; tL += red[1][w * kw + (tx & 63)]; }
             }
-#ifndef ORIANA_GU_NOATOM
             if (colsum_E) atomicAdd(&colsum_E[k], tE);
             if (colsum_Elog) atomicAdd(&colsum_Elog[k], tL);
-#else
-            if (colsum_E && tE == 1.2345) colsum_E[k] = tL;
-#endif
         }
     }
 }
@@ -254,11 +245,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
                 st_f64<VEC>(A.a2 + idx, s2);
                 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-#ifdef ORIANA_GU_ABL_NOSPECIAL                                      /* analysis build: the memory side of the kernel alone */
-                    el[v] = (float)s1[v] - lg2c[v];
-#else
                     el[v] = gamma_meanlog_f32_lg(s1[v], lg2c[v]);
-#endif
             } else if (A.Z_in) {
                 float z[VEC];
                 ld_f32<VEC>(z, A.Z_in + idx);
@@ -294,11 +281,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
             }
             #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-#ifdef ORIANA_GU_ABL_NOSPECIAL
-                e[v] = s1[v] * s2[v];
-#else
                 e[v] = s1[v] / s2[v];                                                       // gamma.py:37-46
-#endif
                 sE[v] += e[v];
                 sL[v] += (double)el[v];
             }
@@ -318,11 +301,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
                 float fu[VEC];
                 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-#if defined(ORIANA_GU_ABL_NOSPECIAL) || defined(ORIANA_GU_ABL_NOEXP)
-                    fu[v] = el[v] - mx;
-#else
                     fu[v] = (float)exp((double)el[v] - (double)mx);
-#endif
                 st_f32<VEC>(A.FUn + row * Kp + k0, fu);
                 if (cg == 0) {
                     A.mu_out[row] = badi ? NAN : mx;

@@ -4,9 +4,12 @@ profiles/: r04_sq_secondary.json (what binds the kernels of configs[2] / configs
 traffic per sweep, with the guide's gfx950 correction spelled out per kernel) -- the `roofline.traffic` of those workloads."""
 import json
 import os
+import sys
+
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r04'            # the round's tag: gpurun_out/<RND>/<RND>_*.json -> profiles/<RND>_*.json
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, 'gpurun_out', 'r04') + '/'
+F = os.path.join(ROOT, 'gpurun_out', RND) + '/'
 P = os.path.join(ROOT, 'profiles') + '/'
 KiB = 1024.0
 ALG = {'c3_zi': 16.0 * 100000 * 20000 + 4.0 * 50 * (2 * 100000 + 2 * 20000) + 4.0 * 50 * 20000,
@@ -18,10 +21,10 @@ SKIP = ('k_dropout_fused', 'k_dropout_fix_nz')         # the float64 A/B leg of 
 sq_all = {}
 for w in ('c3_zi', 'c5_sparse'):
     try:
-        s1 = json.load(open(F + 'r04_%s_sq1.json' % w))['per_dispatch_mean']
-        s2 = json.load(open(F + 'r04_%s_sq2.json' % w))['per_dispatch_mean']
-        fe = json.load(open(F + 'r04_%s_fetch.json' % w))['per_dispatch_mean']
-        wr = json.load(open(F + 'r04_%s_write.json' % w))['per_dispatch_mean']
+        s1 = json.load(open(F + '%s_%s_sq1.json' % (RND, w)))['per_dispatch_mean']
+        s2 = json.load(open(F + '%s_%s_sq2.json' % (RND, w)))['per_dispatch_mean']
+        fe = json.load(open(F + '%s_%s_fetch.json' % (RND, w)))['per_dispatch_mean']
+        wr = json.load(open(F + '%s_%s_write.json' % (RND, w)))['per_dispatch_mean']
     except FileNotFoundError:
         continue
     der = {}
@@ -50,30 +53,31 @@ for w in ('c3_zi', 'c5_sparse'):
         raw[k] = {'FETCH_SIZE': f, 'WRITE_SIZE': wv}
         tr[k] = ((2.0 if any(x in k for x in WIDE) else 1.0) * f + wv) * KiB
     tr['total'] = sum(tr.values())
-    json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload %s --steps 3 --warmup 1 --no-cpu '
-                          '(and a second, separate pass with --pmc WRITE_SIZE); tools/evidence_r04_pmc.sh' % w,
+    json.dump({'command': ('rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload %s --steps 3 --warmup 1 --no-cpu '
+                           '(and a second, separate pass with --pmc WRITE_SIZE); tools/evidence_%s_pmc.sh') % (w, RND),
                'workload': w, 'n_gpus': 1, 'unit': 'KB per launch (one launch of each kernel per sweep), as rocprofv3 reports them',
                'counters': raw,
                'corrections': 'MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read.  Doubled: '
                               + ', '.join(WIDE) + ' (16-byte per-lane record / D_hat streams, LDS-DMA).  The column passes read 8-byte + 2-byte per-lane '
                               'streams plus factor tiles served by L2 / Infinity Cache: taken as counted.  WRITE_SIZE as counted; KB taken as KiB.  Left out: '
                               + ', '.join(SKIP) + ' (the float64 A/B leg of the bench line and the one-time initialisation).',
-               'traffic_bytes_per_pass': tr, 'algorithmic_bytes': ALG[w]}, open(P + 'r04_pmc_hbm_%s.json' % w, 'w'), indent=1)
+               'traffic_bytes_per_pass': tr, 'algorithmic_bytes': ALG[w]}, open(P + '%s_pmc_hbm_%s.json' % (RND, w), 'w'), indent=1)
     print(w, 'traffic per sweep %.1f GB against %.1f GB algorithmic' % (tr['total'] / 1e9, ALG[w] / 1e9), {k[:28]: round(v / 1e9, 2) for k, v in tr.items()})
-json.dump({'command': 'tools/evidence_r04_pmc.sh: two rocprofv3 --pmc passes per workload (8 SQ counters + GRBM_GUI_ACTIVE; counters only with --kernel-trace) over '
+if sq_all:
+  json.dump({'command': 'tools/evidence_' + RND + '_pmc.sh: two rocprofv3 --pmc passes per workload (8 SQ counters + GRBM_GUI_ACTIVE; counters only with --kernel-trace) over '
                       'python3 bench.py --workload {c3_zi, c5_sparse} --steps 3 --warmup 1 --no-cpu',
            'unit': 'per launch; wave-cycle shares of SQ_WAVE_CYCLES; busy fractions of the kernel\'s cycles x 1024 SIMDs',
-           'derived': sq_all}, open(P + 'r04_sq_secondary.json', 'w'), indent=1)
+           'derived': sq_all}, open(P + RND + '_sq_secondary.json', 'w'), indent=1)
 for w, der in sq_all.items():
     for k, e in der.items():
         print(w, k[:40], {a: round(b, 3) for a, b in e.items() if 'fraction' in a or 'wave_cycles' in a})
 
 # ---- C4, hybrid layout, final build (tools/evidence_r04_pmc_c4.sh)
 try:
-    fe = json.load(open(F + 'r04_c4_fetch.json'))['per_dispatch_mean']
-    wr = json.load(open(F + 'r04_c4_write.json'))['per_dispatch_mean']
-    s1 = json.load(open(F + 'r04_c4_sq1.json'))['per_dispatch_mean']
-    s2 = json.load(open(F + 'r04_c4_sq2.json'))['per_dispatch_mean']
+    fe = json.load(open(F + RND + '_c4_fetch.json'))['per_dispatch_mean']
+    wr = json.load(open(F + RND + '_c4_write.json'))['per_dispatch_mean']
+    s1 = json.load(open(F + RND + '_c4_sq1.json'))['per_dispatch_mean']
+    s2 = json.load(open(F + RND + '_c4_sq2.json'))['per_dispatch_mean']
 except FileNotFoundError:
     fe = None
 if fe is not None:
@@ -90,7 +94,7 @@ if fe is not None:
     tr['total'] = sum(tr.values())
     names = ('k_row_pass', 'k_col_pass', 'k_dn_row', 'k_dn_col', 'k_dn_images<6, 1, true>', 'k_dn_images<6, 1, false>', 'k_fixup', 'k_dn_fixup')
     json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu   (and a second, '
-                          'separate pass with --pmc WRITE_SIZE); tools/evidence_r04_pmc_c4.sh', 'workload': 'c4',
+                          'separate pass with --pmc WRITE_SIZE); tools/evidence_' + RND + '_pmc_c4.sh', 'workload': 'c4',
                'layout': 'hybrid, threshold 0.2 (4064 dense genes); the row blocks of the last round of both row kernels split into three gene ranges',
                'n_gpus': 1, 'unit': 'KB per launch, averaged over the launches of the run, as rocprofv3 reports them',
                'counters': {k: {'FETCH_SIZE': g(fe, k), 'WRITE_SIZE': g(wr, k)} for k in names},
@@ -98,7 +102,7 @@ if fe is not None:
                               'row pass (8-byte records as 16-byte per-lane loads), the dense row kernel (counts as 16-byte per-lane loads, operand images by '
                               '16-byte LDS-DMA) and the dense gene-side kernel (s and the operand images by 16-byte LDS-DMA).  The sliced column pass reads 4-byte '
                               'and 1-byte per-lane streams plus factor tiles served by L2 / Infinity Cache: taken as counted.  WRITE_SIZE as counted; KB taken as KiB.',
-               'traffic_bytes_per_pass': tr, 'algorithmic_bytes': 120824000000.0}, open(P + 'r04_pmc_hbm_c4_hybrid.json', 'w'), indent=1)
+               'traffic_bytes_per_pass': tr, 'algorithmic_bytes': 120824000000.0}, open(P + RND + '_pmc_hbm_c4_hybrid.json', 'w'), indent=1)
     sq, der = {}, {}
     for d in (s1, s2):
         for k, dd in d.items():
@@ -114,10 +118,10 @@ if fe is not None:
             e['matrix_pipe_busy_fraction'] = n['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / clk
             e['valu_instructions_per_matrix_instruction'] = n['SQ_INSTS_VALU'] / n['SQ_INSTS_MFMA']
         der[k] = e
-    json.dump({'command': 'tools/evidence_r04_pmc_c4.sh: two rocprofv3 --pmc passes (8 SQ counters + GRBM_GUI_ACTIVE, counters only with --kernel-trace) over '
+    json.dump({'command': 'tools/evidence_' + RND + '_pmc_c4.sh: two rocprofv3 --pmc passes (8 SQ counters + GRBM_GUI_ACTIVE, counters only with --kernel-trace) over '
                           'python3 bench.py --steps 2 --warmup 1 --no-cpu (c4, hybrid layout, final build)',
                'unit': 'per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles',
-               'counters': sq, 'derived': der}, open(P + 'r04_sq_pass_c4_hybrid.json', 'w'), indent=1)
+               'counters': sq, 'derived': der}, open(P + RND + '_sq_pass_c4_hybrid.json', 'w'), indent=1)
     print('c4 hybrid traffic per pass %.1f GB' % (tr['total'] / 1e9), {k: round(v / 1e9, 2) for k, v in tr.items()})
     for k, e in der.items():
         print(k[:40], {a: round(b, 3) for a, b in e.items() if b is not None and ('fraction' in a or 'wave_cycles' in a)})

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Evidence run of round 4, part 3: hardware counters of the pass kernels at full C4 with the hybrid layout on the final build
-# (each --pmc pass on its own, counters only with --kernel-trace).  Filed by tools/assemble_profiles_r04_pmc.py.
+# (each --pmc pass on its own, counters only with --kernel-trace).  Filed by tools/assemble_profiles_pmc.py.
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04
 mkdir -p $O

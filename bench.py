@@ -739,9 +739,10 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
             psum = torch.zeros(m, dtype=torch.float64, device=dev)
             if model._fast_dense:
                 lg = torch.zeros(int(engine._lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device=dev)
-                engine.call('oriana_dropout_sweep_fused', engine.ptr(D_new), engine.ptr(U64), engine.ptr(V64), engine.ptr(model.pi_d.tensor),
-                            engine.ptr(nzm), engine.ptr(psum), None, None, engine.ptr(lg), model._matrix_arith, srows, m, K,
-                            engine.stream_ptr())
+                # (with V_next and the per-lane flags: the kernel the sweep itself launches, csrc/dense_zi.hip for K = 33 .. 100)
+                DV_new = torch.zeros(srows, K, dtype=torch.float64, device=dev)
+                engine.dropout_sweep(D_new, U64, V64, model.pi_d.tensor, nzm, engine.nzmask_tiles(nzm, srows, m), psum, V64, DV_new, lg,
+                                     model._matrix_arith, srows, m, K)
             else:
                 engine.call('oriana_dropout_update_fused', None, engine.ptr(D_new), engine.ptr(U64), engine.ptr(V64),
                             engine.ptr(model.pi_d.tensor), engine.ptr(nzm), engine.ptr(psum), srows, m, K, engine.stream_ptr())
@@ -750,7 +751,7 @@ def cpu_baseline_and_slab(np, torch, engine, model, gen, mname, n_total, m, K, r
                      'DtU_rel': float(np.abs(DtU_h.cpu().numpy() - DtU_ref).max() / max(np.abs(DtU_ref).max(), 1e-300)),
                      'D_hat_abs': float(np.abs(D_new.cpu().numpy().astype(np.float64) - p_ref.astype(np.float32)).max()),
                      'p_d_colsum_rel': float(np.abs(psum.cpu().numpy() - p_ref.sum(0)).max() / max(p_ref.sum(0).max(), 1e-300)),
-                     'dense_arithmetic': 'float64' if not model._fast_dense else ('bf16x3' if model._matrix_arith == 1 and K <= 64 else 'f32 matrix instruction')}
+                     'dense_arithmetic': 'float64' if not model._fast_dense else ('bf16x3' if model._matrix_arith == 1 and K <= 100 else 'f32 matrix instruction')}
         else:
             nest = 'sparse_gap.py:81-97 (S_tilde, S_hat of the model)'
             model._threshold()                       # S_tilde = p_s > tau as the NEXT sweep will take it (sparse_gap.py:113; idempotent)

@@ -475,6 +475,19 @@ int oriana_gamma_update_finalize_prep(double *a1, double *a2, double *E, float *
                                  float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
                                  const double *rate_vec, int64_t r, int64_t K, float *FU_next, float *mu_out, float *upart,
                                  void *stream);
+/* [r6] The finalize form for pCMF's cell side WITHOUT the two (r, K) float64 matrices no kernel of a sweep reads:
+ *   gap.py:98   a2[i, :] = max(1e-15, alpha2 + sum_j V_hat)   -- the same K numbers in every row: written ONCE, to a2_row[K];
+ *   gap.py:101  U_hat = a1 / a2 (Gamma._mean, gamma.py:37-46)  -- not stored; its column sums go to colsum_E as before.
+ * The launch moves 3.2 instead of 4.8 GB at configs[3].  The caller materialises a2 / U_hat on access (oriana_amd/models/gap.py:
+ * a float64 broadcast and a float64 division, bit-identical to what the kernel would have stored).  Everything else as
+ * oriana_gamma_update_finalize_prep.  ORIANA_EKRANGE when no vector kernel serves this K / these pointers (odd K above 64,
+ * K above 256, a pointer that is not 16-byte aligned): take oriana_gamma_update_finalize_prep. */
+int oriana_gamma_update_finalize_lazy(double *a1, double *a2_row, float *Elog,
+                                 double *colsum_E, double *colsum_Elog,
+                                 const double *prior1, const double *prior2,
+                                 float *Z, const float *F, const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
+                                 const double *rate_vec, int64_t r, int64_t K, float *FU_next, float *mu_out, float *upart,
+                                 void *stream);
 
 /* M-step for one Gamma node (gap.py:117-129; utils.py:39-51):
  *   p1 = max(1e-15, nan_to_num(inverse_digamma(log(p2) + f32(colsum_Elog / count))))
@@ -547,6 +560,21 @@ int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, c
                                const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
                                float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K, void *stream);
 int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K);
+/* [r6] The same sweep with the non-zero mask ALSO as per-lane flags for the K = 33 .. 100 bf16 x 3 kernel (csrc/dense_zi.hip,
+ * dn::k_zi_row): every lane of a wave reads the 16 flags of the 16 values it holds with one 2-byte LDS read per tile and
+ * applies the override p_d[X != 0] = 1 - 1e-10 (zigap.py:135) with two instructions per entry (bit-field extract, bit-field
+ * insert) where the gene-major words of oriana_nzmask_f32 took three plus eight LDS reads per tile.
+ * nztiles: oriana_nzmask_tiles_words(n, m) uint32 words (16-byte aligned), built ONCE per count matrix by oriana_nzmask_tiles
+ * from the oriana_nzmask_f32 layout: per (cell tile of 32, gene tile of 32) 64 x 16 bits, bit v of entry l =
+ * (X[32 ct + l % 32, 32 gt + 8 (v / 4) + 4 (l / 32) + v % 4] != 0); cell tiles padded to a multiple of 8.
+ * nztiles == NULL (= oriana_dropout_sweep_fused): that kernel does not apply; K <= 64 takes the bf16 kernels of
+ * csrc/dense_f32.hip, larger K the float32 matrix instruction. */
+int oriana_dropout_sweep_fused_tiles(float *D_hat, const double *U, const double *V, const double *pi_d,
+                                     const uint32_t *nzmask, const uint32_t *nztiles, double *colsum, const double *V_next,
+                                     double *DV_next, float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K,
+                                     void *stream);
+int64_t oriana_nzmask_tiles_words(int64_t n, int64_t m);
+int oriana_nzmask_tiles(uint32_t *tiles, const uint32_t *nzmask, int64_t n, int64_t m, void *stream);
 /* out[m, K] += D_hat^T W[n, K] (zigap.py:124), D_hat streamed once; `out` must be initialised.  arithmetic as above;
  * scratch: oriana_dense_t_scratch_floats(n, K) floats (16-byte aligned; the bf16 operand images of W), may be NULL
  * with ORIANA_MATRIX_F32. */

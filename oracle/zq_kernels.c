@@ -180,3 +180,69 @@ int zq_sparse_zigap(float *DSZ_hat, float *DZ_hat, float *DZ_exp_logsum_hat,
     }
     return 0;
 }
+
+/* ---- the same two nests with the zero counts skipped -------------------------------------------------------------------
+ * For x == 0 every term of gap.py:78-80 / sparse_gap.py:93-97 is (0 * e_k) / den = +0 (or -0 against a negative log sum):
+ * adding it changes no sum.  So zq_gap_nz / zq_sparse_gap_nz return bit for bit what zq_gap / zq_sparse_gap return WHENEVER
+ * every expf(lu + lv) is finite (an overflowed term would make 0 * inf = NaN in the full nest) -- tests/test_oracle.py pins
+ * that identity on the golden kernel I/O and on random inputs.  They exist so that -m gpu tests can run whole oracle sweeps at
+ * sizes where the kernels of the benchmarked configurations engage (n K >= 2^20: 1e8 entries x K exponentials in the full
+ * nest, 96 % of them for zero counts). */
+int zq_gap_nz(float *Z_hat_i, float *Z_hat_j,
+              const float *log_U_hat, const float *log_V_hat, const float *X,
+              int64_t n, int64_t p, int64_t K)
+{
+    if (K > MAXK) return -1;
+    float e[MAXK];
+    memset(Z_hat_i, 0, sizeof(float) * (size_t)(n * K));
+    memset(Z_hat_j, 0, sizeof(float) * (size_t)(p * K));
+    for (int64_t i = 0; i < n; i++) {
+        const float *lu = log_U_hat + i * K;
+        for (int64_t j = 0; j < p; j++) {
+            const float x = X[i * p + j];
+            if (x == 0.0f) continue;
+            const float *lv = log_V_hat + j * K;
+            for (int64_t k = 0; k < K; k++) e[k] = expf(lu[k] + lv[k]);
+            float den = np_pairwise_sum_f32(e, K);
+            den = (den > 0) ? den : 1.0f;
+            for (int64_t k = 0; k < K; k++) {
+                float expectation = (x * e[k]) / den;
+                Z_hat_j[j * K + k] += expectation;
+                Z_hat_i[i * K + k] += expectation;
+            }
+        }
+    }
+    return 0;
+}
+
+int zq_sparse_gap_nz(float *SZ_hat_i, float *Z_hat_j, float *Z_exp_logsum_hat,
+                     const float *log_U_hat, const float *log_V_hat,
+                     const float *S_tilde, const float *S_hat, const float *X,
+                     int64_t n, int64_t p, int64_t K)
+{
+    if (K > MAXK) return -1;
+    float e[MAXK], ls[MAXK];
+    memset(SZ_hat_i, 0, sizeof(float) * (size_t)(n * K));
+    memset(Z_hat_j, 0, sizeof(float) * (size_t)(p * K));
+    memset(Z_exp_logsum_hat, 0, sizeof(float) * (size_t)(p * K));
+    for (int64_t i = 0; i < n; i++) {
+        const float *lu = log_U_hat + i * K;
+        for (int64_t j = 0; j < p; j++) {
+            const float x = X[i * p + j];
+            if (x == 0.0f) continue;
+            const float *lv = log_V_hat + j * K;
+            const float *st = S_tilde + j * K;
+            const float *sh = S_hat + j * K;
+            for (int64_t k = 0; k < K; k++) { ls[k] = lu[k] + lv[k]; e[k] = expf(ls[k]) * st[k]; }
+            float den = np_pairwise_sum_f32(e, K);
+            den = (den > 0) ? den : 1.0f;
+            for (int64_t k = 0; k < K; k++) {
+                float expectation = (x * e[k]) / den;
+                SZ_hat_i[i * K + k] += sh[k] * expectation;
+                Z_hat_j[j * K + k] += expectation;
+                Z_exp_logsum_hat[j * K + k] += expectation * ls[k];
+            }
+        }
+    }
+    return 0;
+}

@@ -108,6 +108,7 @@ _SIGS = {
     'oriana_gamma_update_prep_blocks': (_I, [_I, _I]),
     'oriana_gamma_update_prep': (c_int, [_P] * 13 + [_I, _I, _P, _P, _P, _P]),
     'oriana_gamma_update_finalize_prep': (c_int, [_P] * 11 + [_I, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
+    'oriana_gamma_update_finalize_lazy': (c_int, [_P] * 10 + [_I, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     'oriana_mstep_gamma_pair': (c_int, [_P, _P, _P, _P, c_double, _P, _P, _P, _P, c_double, _P, _I, _P]),
     'oriana_colsum_f64': (c_int, [_P, _P, _P, _I, _I, _P]),
     'oriana_dropout_update': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
@@ -115,6 +116,9 @@ _SIGS = {
     'oriana_dense_times_factor': (c_int, [_P, _P, _P, _I, _I, _I, c_int, _P]),
     'oriana_dropout_sweep_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _I, _I, _I, _P]),
     'oriana_dropout_sweep_scratch_floats': (_I, [_I, _I]),
+    'oriana_dropout_sweep_fused_tiles': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _I, _I, _I, _P]),
+    'oriana_nzmask_tiles_words': (_I, [_I, _I]),
+    'oriana_nzmask_tiles': (c_int, [_P, _P, _I, _I, _P]),
     'oriana_dense_t_times_factor_f32': (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _P]),
     'oriana_dense_t_scratch_floats': (_I, [_I, _I]),
     'oriana_factor_cast_f32': (c_int, [_P, _P, _P, _P, _I, _I, _P]),

@@ -838,13 +838,16 @@ static int64_t pick_splits(int64_t blocks, int64_t max_splits) {
 // [r5] lgs (may be NULL): the same as -logit * log2(e) -- the form dn::k_zi_row takes: its sigmoid is
 // 1 / (1 + exp2(fma(Lambda, log2 e, lgs))), one fused multiply-add where the subtraction and the scaling were two instructions
 // per entry (floating-point vector work beside matrix instructions is the dear kind on this part, DESIGN.md 10 i)
-__global__ void k_logit_f32(float *__restrict__ lg, float *__restrict__ lgs, const double *__restrict__ pi_d, int64_t m) {
+// [r6] flo (with lgs): the floor dn::k_zi_row ADDS to its sigmoid -- 1e-10 where pi_d <= 0 (there lgs = +inf makes the sigmoid
+// +0: the column override of zigap.py:133 as one addition), 0 elsewhere.
+__global__ void k_logit_f32(float *__restrict__ lg, float *__restrict__ lgs, float *__restrict__ flo,
+                            const double *__restrict__ pi_d, int64_t m) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const double pi = pi_d[j];
     const float v = (pi <= 0.0) ? -INFINITY : (pi >= 1.0) ? INFINITY : (float)logit_f64(pi);
     lg[j] = v;
-    if (lgs) lgs[j] = -v * 1.4426950408889634f;
+    if (lgs) { lgs[j] = -v * 1.4426950408889634f; flo[j] = (pi <= 0.0) ? 1e-10f : 0.0f; }
 }
 
 template <int NT>
@@ -892,6 +895,9 @@ __global__ __launch_bounds__(256) void k_split_rows(u4v *__restrict__ img, const
     for (int sp = 0; sp < 3; ++sp) dst[sp * 64] = o[sp];
 }
 
+#ifndef ORIANA_ZI_TILEMAJOR
+#define ORIANA_ZI_TILEMAJOR 0
+#endif
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restrict__ out, const float *__restrict__ D,
                                                                 const u4v *__restrict__ img, int64_t n, int64_t m, int K,
@@ -948,7 +954,12 @@ __global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restri
     // matrix -- one running pointer, eight plain loads per chunk
     auto group = [&](auto fast_tag, int64_t i0, bool more) {
         constexpr bool FAST = decltype(fast_tag)::value;
+#if ORIANA_ZI_TILEMAJOR           // (timing experiment: D_hat as [cell tile][gene tile][32 x 32]; a group of 32 rows = one tile)
+        const int64_t ngt_ = (m + 31) / 32;
+        const float *dp = D + (((i0 + 16 * CH) >> 5) * ngt_ + (jw >> 5)) * 1024 + (8 * h) * 32 + c;
+#else
         const float *dp = D + (i0 + 16 * CH + 8 * h) * m + j;    // (dereferenced on the fast path only)
+#endif
         stage_load(more ? i0 + 16 * CH : i0);                    // (unconditional: the last group is staged again, unread)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -959,8 +970,13 @@ __global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restri
             if (FAST) {
                 const float *r = dp;
 #pragma unroll
+#if ORIANA_ZI_TILEMAJOR
+                for (int e = 0; e < 8; ++e) { ring[ch][e] = *r; r += 32; }
+                dp += 16 * 32;
+#else
                 for (int e = 0; e < 8; ++e) { ring[ch][e] = *r; r += m; }
                 dp += 16 * m;
+#endif
             } else {
                 load_checked(ring[ch], i0 + 16 * (ch + CH));
             }
@@ -1063,8 +1079,10 @@ bool zi_supported(int64_t m, int64_t K);
 bool zi_dt_supported(int64_t m, int64_t K);
 int64_t zi_sweep_image_floats(int64_t m);
 int64_t zi_dt_image_floats(int64_t n);
-int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, const uint32_t *nzmask, double *colsum,
-             const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m, int K, hipStream_t st);
+int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, int64_t mpad, const uint32_t *nztiles,
+             double *colsum, const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m, int K, hipStream_t st);
+int64_t zi_tiles_words(int64_t n, int64_t m);
+int zi_tiles(uint32_t *out, const uint32_t *nzmask, int64_t n, int64_t m, hipStream_t st);
 int zi_dt(double *out, const float *D, const double *W, float *scratch, int64_t n, int64_t m, int K, hipStream_t st);
 }  // namespace dn
 
@@ -1078,12 +1096,28 @@ extern "C" int64_t oriana_dropout_sweep_scratch_floats(int64_t m, int64_t K) {
     // images of csrc/dense_zi.hip for 64 < K <= 100)
     const int64_t a = b16_img_floats(m, 4 * 3 * 64) + b16_img_floats(m, 2 * 2 * 3 * 64);
     const int64_t b = (K > 32 && K <= 100) ? dn::zi_sweep_image_floats(m) : 0;
-    return 2 * ((m + 63) / 64 * 64) + (a > b ? a : b);       // logits, scaled logits (dense_zi.hip), images
+    return 3 * ((m + 63) / 64 * 64) + (a > b ? a : b);       // logits, scaled logits + floors (dense_zi.hip), images
 }
 
-extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d64,
-                                          const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
-                                          float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K, void *stream) {
+extern "C" int64_t oriana_nzmask_tiles_words(int64_t n, int64_t m) {
+    if (n < 0 || m < 0) return 0;
+    return dn::zi_tiles_words(n, m);
+}
+
+extern "C" int oriana_nzmask_tiles(uint32_t *tiles, const uint32_t *nzmask, int64_t n, int64_t m, void *stream) {
+    if (n < 0 || m < 0) return ORIANA_EINVAL;
+    if (n == 0 || m == 0) return 0;
+    if (!tiles || !nzmask || ((uintptr_t)tiles & 15) != 0) return ORIANA_EINVAL;
+    const int rc = dn::zi_tiles(tiles, nzmask, n, m, (hipStream_t)stream);
+    if (rc) return rc;
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int oriana_dropout_sweep_fused_tiles(float *D_hat, const double *U, const double *V, const double *pi_d64,
+                                                const uint32_t *nzmask, const uint32_t *nztiles, double *colsum,
+                                                const double *V_next, double *DV_next, float *scratch, int arithmetic,
+                                                int64_t n, int64_t m, int64_t K, void *stream) {
     if (n < 0 || m < 0 || K <= 0) return ORIANA_EINVAL;
     if (K > 128) return ORIANA_EKRANGE;
     if (n == 0 || m == 0) return 0;
@@ -1092,12 +1126,14 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
     if (arithmetic != ORIANA_MATRIX_F32 && arithmetic != ORIANA_MATRIX_BF16X3) return ORIANA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int64_t mpad = (m + 63) / 64 * 64;
-    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, scratch + mpad, pi_d64, m);
+    hipLaunchKernelGGL(k_logit_f32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, scratch, scratch + mpad, scratch + 2 * mpad,
+                       pi_d64, m);
     const float *pi_d = scratch;
-    scratch += mpad;                                   // (the scaled logits; the operand images follow them)
+    scratch += mpad;                                   // (the scaled logits and the floors; the operand images follow them)
     int rc = ORIANA_EKRANGE;
-    if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nzmask && dn::zi_supported(m, K))
-        rc = dn::zi_sweep(D_hat, U, V, scratch, nzmask, colsum, V_next, DV_next, scratch + mpad, n, m, (int)K, st);
+    if (arithmetic == ORIANA_MATRIX_BF16X3 && V_next && nztiles && dn::zi_supported(m, K))
+        rc = dn::zi_sweep(D_hat, U, V, scratch, mpad, nztiles, colsum, V_next, DV_next, scratch + 2 * mpad, n, m, (int)K, st);
+    scratch += mpad;
     if (rc != ORIANA_EKRANGE) {
         // (done, or failed for good; ORIANA_EKRANGE = not this kernel's case, e.g. a D_hat that is not 16-byte aligned)
     } else if (arithmetic == ORIANA_MATRIX_BF16X3 && K <= 64) {
@@ -1119,6 +1155,15 @@ extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const d
     if (rc) return rc;
     ORIANA_LAUNCH_CHECK();
     return 0;
+}
+
+// the round-2 entry: without the per-lane flags (oriana_nzmask_tiles) the K = 33 .. 100 kernel of csrc/dense_zi.hip does not apply (K <= 64 takes
+// the bf16 kernels of this file, the rest the float32 matrix instruction)
+extern "C" int oriana_dropout_sweep_fused(float *D_hat, const double *U, const double *V, const double *pi_d64,
+                                          const uint32_t *nzmask, double *colsum, const double *V_next, double *DV_next,
+                                          float *scratch, int arithmetic, int64_t n, int64_t m, int64_t K, void *stream) {
+    return oriana_dropout_sweep_fused_tiles(D_hat, U, V, pi_d64, nzmask, nullptr, colsum, V_next, DV_next, scratch, arithmetic, n, m,
+                                            K, stream);
 }
 
 extern "C" int64_t oriana_dense_t_scratch_floats(int64_t n, int64_t K) {

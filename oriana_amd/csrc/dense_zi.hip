@@ -80,23 +80,36 @@ __global__ __launch_bounds__(512) void k_zi_images(u4v *__restrict__ img, const 
 
 // ---- D update -------------------------------------------------------------------------------------------------------
 // The per-tile side data ride in the padding of the image ring: a gene-side image is PV_RAW pieces (a multiple of 64)
-// copied as PV = multiple of 512; the wave whose 64-piece slot is the first padding one copies the 8 waves' mask words
-// instead (nzmask[cell tile of wave l / 8][genes 4 (l % 8) ..]: 128 bytes per wave), the next one logit(pi_d) of the
-// tile's 32 genes.  They arrive with the image, two tiles ahead, and cost no LDS of their own.
+// copied as PV = multiple of 512; the wave whose 64-piece slot is the first padding one copies the 8 waves' non-zero flags
+// instead (128 bytes per wave and tile, below), the next one -- from lgit[0 .. 2 mpad) -- the scaled logits of the tile's 32
+// genes (lanes 0-7) and their floors (lanes 8-15: 1e-10 where pi_d <= 0, else 0).  They arrive with the image, two tiles
+// ahead, and cost no LDS of their own.
+//
+// [r6] The non-zero flags come PER LANE (oriana_nzmask_tiles): for cell tile ct and gene tile gt, 64 x 16 bits, bit v of
+// entry l = (X[32 ct + l % 32, 32 gt + 8 (v / 4) + 4 (l / 32) + v % 4] != 0) -- the 16 values lane l of the wave holds, in
+// register order.  One 2-byte LDS read per lane and tile, then v_bfe_i32 (flag -> 0 / ~0) + v_bfi_b32 (select 1.0f) per value:
+// round 3 read the mask words of oriana_nzmask_f32 (bit = cell) and spent and + compare + select per value on the lane's bit.
+#ifndef ORIANA_ZI_TILEMAJOR
+#define ORIANA_ZI_TILEMAJOR 0
+#endif
+#ifndef ORIANA_ZI_MASK_SMEM
+#define ORIANA_ZI_MASK_SMEM 0          // 1 (experiment): the same 128 bytes as 16 pair-ordered 64-bit lane masks, scalar loads
+#endif
 template <int KC, int TAIL>
-__device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const uint32_t *__restrict__ nzmask,
-                                            const float *__restrict__ lgit, u4v *dst, int gt, int64_t ct_blk0, int mrow_l,
-                                            int64_t m, int w, int lane) {
+__device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const uint32_t *__restrict__ nztiles,
+                                            const float *__restrict__ lgit, int64_t mpad, u4v *dst, int gt, int64_t ct_blk0,
+                                            int ngt, int64_t m, int w, int lane) {
     // Every copy is  wave-uniform base (scalar registers) + 32-bit lane offset , both chosen WITHOUT a branch: the loop
     // body of k_zi_row must stay one basic block (a predicated copy, or a select between per-lane 64-bit pointers, is
     // compiled into control flow / costs the registers the kernel does not have).  Clamped, never predicated: what a
     // clamped lane fetches belongs to padding cells / genes, whose values are neither stored nor summed.
     using C = Cfg<KC, TAIL>;
     constexpr int SLOT0 = C::PV_RAW / 64;
-    static_assert(C::PV_RAW % 64 == 0 && C::PV / 64 >= SLOT0 + 2, "the image padding holds the mask and logit pieces");
+    static_assert(C::PV_RAW % 64 == 0 && C::PV / 64 >= SLOT0 + 2, "the image padding holds the flag and logit pieces");
     const int64_t j0 = (int64_t)gt * 32;
     const char *ibase = reinterpret_cast<const char *>(imgV + (int64_t)gt * C::PV);
-    const char *mbase = reinterpret_cast<const char *>(nzmask + ct_blk0 * m + j0);
+    // (the flag array covers whole work-groups of 8 cell tiles: no clamp; lane l copies piece l % 8 of wave l / 8)
+    const char *mbase = reinterpret_cast<const char *>(nztiles + (ct_blk0 * ngt + gt) * 32);
     const char *lbase = reinterpret_cast<const char *>(lgit + j0);
     const int jlim = (int)((m - 4 - j0 < 252) ? m - 4 - j0 : 252);          // last whole 16-byte piece of the row (>= 0)
 #pragma unroll
@@ -105,9 +118,10 @@ __device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const 
         const char *base = ibase;
         uint32_t voff = (uint32_t)(slot * 64 + lane) * 16u;                // an image piece (or its padding: harmless)
         if (p * NW + NW - 1 >= SLOT0) {
-            const int jm = min(4 * (lane & 7), jlim), jl = min(4 * lane, jlim);
-            const uint32_t moff = ((uint32_t)mrow_l * (uint32_t)m + (uint32_t)jm) * 4u;   // < 8 m + 128 bytes x 4
-            const uint32_t loff = (uint32_t)jl * 4u;
+            const int l8 = lane & 7;
+            const uint32_t moff = (uint32_t)(lane >> 3) * (uint32_t)ngt * 128u + (uint32_t)l8 * 16u;   // < 8 ngt x 128 bytes
+            const int jl = min(4 * ((lane < 16) ? l8 : lane), jlim);
+            const uint32_t loff = ((uint32_t)jl + (((lane >> 3) == 1) ? (uint32_t)mpad : 0u)) * 4u;
             base = (slot == SLOT0) ? mbase : (slot == SLOT0 + 1) ? lbase : ibase;
             voff = (slot == SLOT0) ? moff : (slot == SLOT0 + 1) ? loff : voff;
         }
@@ -117,12 +131,12 @@ __device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const 
 }
 
 template <int KC, int TAIL>
-constexpr int zi_row_lds_bytes() { return 3 * Cfg<KC, TAIL>::PV * 16 + NW * 32 * TS * 4 + 2 * NW * 32 * 4; }
+constexpr int zi_row_lds_bytes() { return 3 * Cfg<KC, TAIL>::PV * 16 + NW * 32 * 32 * 4 + 2 * NW * 32 * 4; }
 
 template <int KC, int TAIL>
 __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const double *__restrict__ U,
-                                                const u4v *__restrict__ imgV, const float *__restrict__ lgit,
-                                                const uint32_t *__restrict__ nzmask, double *__restrict__ colsum,
+                                                const u4v *__restrict__ imgV, const float *__restrict__ lgit, int64_t mpad,
+                                                const uint32_t *__restrict__ nztiles, double *__restrict__ colsum,
                                                 double *__restrict__ DV, int64_t n, int64_t m, int K, int ngt,
                                                 int gt_per_split) {
     using C = Cfg<KC, TAIL>;
@@ -133,14 +147,17 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     u4v *img = ldsq;                                                      // [3][PV]
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *T = reinterpret_cast<float *>(ldsq + 3 * C::PV) + w * 32 * TS;  // [wave][32 cells][TS]
-    float *csb = reinterpret_cast<float *>(ldsq + 3 * C::PV) + NW * 32 * TS;   // [2][8 waves][32 genes]
+    float *T = reinterpret_cast<float *>(ldsq + 3 * C::PV) + w * 32 * 32;  // [wave][32 cells][32 genes], 16-byte chunks swizzled
+    float *csb = reinterpret_cast<float *>(ldsq + 3 * C::PV) + NW * 32 * 32;   // [2][8 waves][32 genes]
     const int64_t ct_blk0 = (int64_t)blockIdx.x * NW;
     const int64_t ct = ct_blk0 + w;                                        // this wave's cell tile
     const int64_t i = ct * 32 + c;
     const int64_t nmrows = (n + 31) / 32;
-    // mask row (relative to the work-group's first cell tile) lane l copies for wave l / 8, clamped to the last one
-    const int mrow_l = (int)((ct_blk0 + (lane >> 3) < nmrows) ? (lane >> 3) : (nmrows - 1 - ct_blk0 > 0 ? nmrows - 1 - ct_blk0 : 0));
+#if ORIANA_ZI_MASK_SMEM
+    // (experiment) the wave's 16 lane masks of a tile by SCALAR loads: {word of gene 8 q + e, word of gene 8 q + 4 + e} IS the
+    // lane mask of value 4 q + e -- one v_cndmask per value, but the loads share the LDS counter
+    const uint64_t *mzrow = reinterpret_cast<const uint64_t *>(nztiles) + ct * (int64_t)ngt * 16;
+#endif
     const int gt0 = blockIdx.y * gt_per_split;
     const int gt1 = (gt0 + gt_per_split < ngt) ? gt0 + gt_per_split : ngt;
     if (gt0 >= gt1) return;
@@ -176,16 +193,28 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
         for (int v = 0; v < 16; ++v) rs[nt][v] = 0.f;
 
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-    float *Tw = T + c * TS + 4 * h;                                        // + 8 q: p[cell c][genes 8 q + 4 h ..]
+    // The transpose buffer: row = cell (32 floats = 8 chunks of 16 bytes), chunk j of row r stored at chunk j ^ (r & 7).
+    // Writes (ds_write_b128: 8 consecutive lanes per LDS cycle, bank = dword % 32): lanes c .. c + 7 write chunk 2 q + h of
+    // rows c .. c + 7 -> eight different physical chunks.  Read-back (ds_read_b128: groups {0-3, 12-15, 20-27}, {4-11, 16-19,
+    // 28-31} (+ 32), bank = dword % 64): lane l reads chunk l % 8 of row l / 8 + 8 q; odd rows sit in the upper half of the
+    // bank row, and inside a group the lanes of two even (odd) rows take the two halves of their 128 bytes: no conflict
+    // either way (round 5: 36-float rows, every read group 2-way: profiles/r05 SQ_LDS_BANK_CONFLICT 10.4 %).
     const int rr = lane >> 3, gq = (lane & 7) * 4;
-    const float *Tr = T + rr * TS + gq;                                    // + 8 q TS: row of cell rr + 8 q, genes gq ..
+    const uint32_t Tw0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)T + (uint32_t)(c * 128 + ((h ^ (c & 7)) * 16));
+    const float *Tr = T + rr * 32 + (((lane & 7) ^ rr) * 4);               // + 8 q rows: row of cell rr + 8 q, genes gq ..
     // D_hat leaves through a buffer resource over the wave's (at most 32) rows: a row beyond the matrix is beyond the
     // resource's size and the hardware drops the store -- no predicate, no branch; a piece beyond the last gene gets an
     // offset that is out of range.  (num_records <= 32 m floats: 32-bit for any m below 3e7)
     const int64_t rows_here = (n - ct * 32 < 0) ? 0 : (n - ct * 32 > 32 ? 32 : n - ct * 32);
+#if ORIANA_ZI_TILEMAJOR        // (timing experiment: D_hat as [cell tile][gene tile][32 x 32]; every store 1 KB contiguous)
+    __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(D_hat + (rows_here > 0 ? ct * (int64_t)ngt * 1024 : 0), 0,
+                                                                     (int)(rows_here > 0 ? (int64_t)ngt * 4096 : 0), 0x00020000);
+    const uint32_t dvoff = (uint32_t)lane * 16u;
+#else
     __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(D_hat + (rows_here > 0 ? ct * 32 * m : 0), 0,
                                                                      (int)(rows_here * m * 4), 0x00020000);
     const uint32_t dvoff = ((uint32_t)rr * (uint32_t)m + (uint32_t)gq) * 4u;
+#endif
     const int rleft = (int)rows_here - rr;                                 // row rr + 8 q of the read-back is a cell iff 8 q < rleft
 
     auto phase_D = [&](const u4v *im) -> f16v {
@@ -221,8 +250,13 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
         }
     };
 
-    zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img, gt0, ct_blk0, mrow_l, m, w, lane);
-    zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img + C::PV, (gt0 + 1 < gt1) ? gt0 + 1 : gt0, ct_blk0, mrow_l, m, w, lane);
+    zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img, gt0, ct_blk0, ngt, m, w, lane);
+    zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + C::PV, (gt0 + 1 < gt1) ? gt0 + 1 : gt0, ct_blk0, ngt, m, w, lane);
+#if ORIANA_ZI_MASK_SMEM
+    uint64_t mk[16];                     // the lane masks of tile gt (loaded one tile ahead, right before the tile barrier)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mk[e] = mzrow[(int64_t)gt0 * 16 + e];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f16v dn = phase_D(img);              // Lambda^T of tile gt0
@@ -239,7 +273,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
         // matrix work for the long loops (item 16 below; measured at 100k x 20k: 5.10 against 5.26 ms at K = 100, 4.38 / 4.46
         // at K = 80), here at the top for KC <= 3 (3.45 against 3.78 ms at K = 48)
         if (DMA_TOP)
-            zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, mrow_l, m,
+            zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, ngt, m,
                                   w, lane);
         u4v A0[2], A1, A2;
         A2 = im1[2 * 64 + lane]; A0[0] = im1[0 * 64 + lane]; A1 = im1[1 * 64 + lane];
@@ -256,8 +290,10 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
         float tl0 = 0.f, tl2 = 0.f;
         const f4v *tails = reinterpret_cast<const f4v *>(im0 + C::P1 + C::P2);
         f4v t2 = {0.f, 0.f, 0.f, 0.f};
-        f4v lg4 = {0.f, 0.f, 0.f, 0.f};
-        u4v mk4 = {0u, 0u, 0u, 0u};
+        f4v lg4 = {0.f, 0.f, 0.f, 0.f}, fl4 = {0.f, 0.f, 0.f, 0.f};
+#if !ORIANA_ZI_MASK_SMEM
+        const int nzw = (int)reinterpret_cast<const uint16_t *>(im0 + MP)[w * 64 + lane];      // this lane's 16 non-zero flags
+#endif
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             if (u < KC * 6) {
@@ -285,31 +321,48 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
             for (int it = (u * NITEM) / NA; it < ((u + 1) * NITEM) / NA; ++it) {
                 if (it < 16) {
                     const int v = it, q = v >> 2;
-                    if ((v & 3) == 0) {              // logits and mask words of the genes 8 q + 4 h .. + 3
+                    if ((v & 3) == 0) {              // scaled logits and floors of the genes 8 q + 4 h .. + 3
                         lg4 = __builtin_bit_cast(f4v, im0[MP + 64 + 2 * q + h]);
-                        mk4 = im0[MP + w * 8 + 2 * q + h];
+                        fl4 = __builtin_bit_cast(f4v, im0[MP + 64 + 8 + 2 * q + h]);
                     }
                     // lgs = -logit(pi_d) log2(e) (k_logit_f32): sigmoid(logit - Lambda) = 1 / (1 + exp2(Lambda log2(e) + lgs))
                     const float lgs = lg4[v & 3];
                     float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(l0[v], 1.4426950408889634f, lgs)));
-                    p = (lgs == INFINITY) ? 1e-10f : p;                   // pi_d <= 0 (lgs = +inf)           zigap.py:133
-                    p = ((mk4[v & 3] >> c) & 1u) ? 1.0f : p;              // X != 0: f32(1 - 1e-10) == 1      zigap.py:135
+                    // pi_d <= 0: lgs = +inf -> exp2 = inf -> p = +0, and the gene's floor is 1e-10; every other gene: + 0 (zigap.py:133)
+                    p += fl4[v & 3];
+#if ORIANA_ZI_MASK_SMEM
+                    p = __builtin_amdgcn_inverse_ballot_w64(mk[v]) ? 1.0f : p;   // X != 0: f32(1 - 1e-10) == 1      zigap.py:135
+#else
+                    {
+                        // X != 0: f32(1 - 1e-10) == 1 (zigap.py:135).  (inline assembly: the compiler turns the same two
+                        // operations written in C into shift + compare + select + and + or)
+                        uint32_t sel;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(nzw), "n"(v));            // flag v -> 0 or ~0
+                        asm("v_bfi_b32 %0, %1, 1.0, %2" : "=v"(p) : "v"(sel), "v"(p));            // (sel & 1.0f) | (~sel & p)
+                    }
+#endif
                     l0[v] = p;
-                    if ((v & 3) == 3) *reinterpret_cast<f4v *>(Tw + 8 * q) = f4v{l0[v - 3], l0[v - 2], l0[v - 1], l0[v]};
+                    if ((v & 3) == 3)
+                        *reinterpret_cast<__attribute__((address_space(3))) f4v *>(Tw0 ^ (uint32_t)(q << 5)) =
+                            f4v{l0[v - 3], l0[v - 2], l0[v - 1], l0[v]};
                 } else if (it == 16) {
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const f4v *>(Tr + 8 * q * TS);
+                    for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const f4v *>(Tr + 8 * q * 32);
                     if (!DMA_TOP)
-                        zi_tile_dma<KC, TAIL>(imgV, nzmask, lgit, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0,
-                                              mrow_l, m, w, lane);
+                        zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, ngt, m,
+                                  w, lane);
                 } else if (it == 17) {
                     // D_hat rows out
                     const uint32_t vo = (j0 + gq < m) ? dvoff : 0x80000000u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
+#if ORIANA_ZI_TILEMAJOR
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, tq[q]), drsrc, vo, (int)(gt * 4096 + q * 1024), 0);
+#else
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, tq[q]), drsrc, vo,
                                                                (int)((j0 + (int64_t)8 * q * m) * 4), 0);
+#endif
                     // sum_i p_d of the wave's 32 cells: lanes with the same lane % 8 hold the same four genes
                     // (padding cells -- only the matrix's last cell tile has any -- enter with weight 0)
                     f4v cs4 = tq[0] * (0 < rleft ? 1.f : 0.f);
@@ -377,6 +430,13 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if ORIANA_ZI_MASK_SMEM
+        {
+            const uint64_t *mz = mzrow + (int64_t)((gt + 1 < gt1) ? gt + 1 : gt) * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mk[e] = mz[e];
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -611,10 +671,55 @@ bool zi_dt_supported(int64_t m, int64_t K) {                               // D_
 int64_t zi_sweep_image_floats(int64_t m) { return ((m + 31) / 32) * (int64_t)Cfg<6, 1>::PV * 4; }
 int64_t zi_dt_image_floats(int64_t n) { return ((n + 31) / 32 + 2) * (int64_t)Cfg<6, 1>::PU * 4; }
 
-int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit /* scaled: -logit log2(e) */, const uint32_t *nzmask, double *colsum,
-             const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m, int K, hipStream_t st) {
+// [r6] The non-zero flags of a (cell tile, gene tile) pair in the order k_zi_row's lanes hold their values: 64 x 16 bits
+// (zi_tile_dma), for ceil(n / 256) x 8 cell tiles (whole work-groups: tiles beyond the matrix are zero) x ceil(m / 32) gene
+// tiles x 128 bytes.  Built once per count matrix (the mask is constant) from the oriana_nzmask_f32 layout.
+__global__ void k_nzmask_tiles(uint32_t *__restrict__ out, const uint32_t *__restrict__ nzmask, int64_t nct, int64_t nct8,
+                               int64_t m, int ngt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one dword each
+    if (t >= nct8 * ngt * 32) return;
+    const int d = (int)(t & 31);
+    const int64_t tile = t >> 5, ct = tile / ngt;
+    const int gt = (int)(tile - ct * ngt);
+    uint32_t o = 0u;
+    if (ct < nct) {
+#if ORIANA_ZI_MASK_SMEM
+        const int pr = d >> 1, hh = d & 1, q = pr >> 2, e = pr & 3;        // entry 4 q + e = {gene 8 q + e, gene 8 q + 4 + e}
+        const int64_t j = (int64_t)gt * 32 + 8 * q + 4 * hh + e;
+        o = (j < m) ? nzmask[ct * m + j] : 0u;
+#else
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                             // dword d = lanes 2 d, 2 d + 1
+            const int l = 2 * d + half, c = l & 31, h = l >> 5;
+            uint32_t f = 0u;
+            for (int v = 0; v < 16; ++v) {
+                const int64_t j = (int64_t)gt * 32 + 8 * (v >> 2) + 4 * h + (v & 3);
+                if (j < m) f |= ((nzmask[ct * m + j] >> c) & 1u) << v;
+            }
+            o |= f << (16 * half);
+        }
+#endif
+    }
+    out[t] = o;
+}
+
+int64_t zi_tiles_words(int64_t n, int64_t m) { return (((n + 31) / 32 + NW - 1) / NW * NW) * ((m + 31) / 32) * 32; }
+
+int zi_tiles(uint32_t *out, const uint32_t *nzmask, int64_t n, int64_t m, hipStream_t st) {
+    const int64_t words = zi_tiles_words(n, m);
+    if (words == 0) return 0;
+    if (words > 0x7fffffffLL * 256) return ORIANA_EINVAL;
+    const int64_t nct = (n + 31) / 32;
+    hipLaunchKernelGGL(k_nzmask_tiles, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, out, nzmask, nct,
+                       (nct + NW - 1) / NW * NW, m, (int)((m + 31) / 32));
+    return 0;
+}
+
+// lgit: [0, mpad) the scaled logits -logit(pi_d) log2(e), [mpad, 2 mpad) the floors (k_logit_f32)
+int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, int64_t mpad, const uint32_t *nztiles,
+             double *colsum, const double *Vn, double *DV, float *img_scratch, int64_t n, int64_t m, int K, hipStream_t st) {
     int kc, tl;
-    if (!zi_cfg(K, &kc, &tl) || (m % 4) != 0 || m > 16000000 || !Vn || !DV || !nzmask) return ORIANA_EKRANGE;
+    if (!zi_cfg(K, &kc, &tl) || (m % 4) != 0 || m > 16000000 || !Vn || !DV || !nztiles) return ORIANA_EKRANGE;
     const int ngt = (int)((m + 31) / 32);
     const int64_t blocks = ((n + 31) / 32 + NW - 1) / NW;
     int64_t splits = zi_pick_splits(blocks, (ngt + 7) / 8);
@@ -622,7 +727,8 @@ int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit /
     splits = (ngt + per - 1) / per;
     if (blocks > 0x7fffffffLL || splits > 65535) return ORIANA_EINVAL;
     u4v *img = reinterpret_cast<u4v *>(img_scratch);
-    if (((reinterpret_cast<uintptr_t>(D_hat) | reinterpret_cast<uintptr_t>(lgit) | reinterpret_cast<uintptr_t>(nzmask)) & 15) != 0)
+    if (((reinterpret_cast<uintptr_t>(D_hat) | reinterpret_cast<uintptr_t>(lgit) | (uintptr_t)(mpad * 4) |
+          reinterpret_cast<uintptr_t>(nztiles)) & 15) != 0 || (int64_t)ngt * 8 * 128 > 0x7fffffffLL)
         return ORIANA_EKRANGE;                                             // 16-byte pieces: the caller falls back
 #define ORIANA_ZI_CALL(KC, TL)                                                                                              \
     do {                                                                                                                    \
@@ -631,7 +737,7 @@ int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit /
         const int rc = zi_set_lds(k_zi_row<KC, TL>, lb);                                                                    \
         if (rc) return rc;                                                                                                  \
         hipLaunchKernelGGL((k_zi_row<KC, TL>), dim3((unsigned)blocks, (unsigned)splits), dim3(512), lb, st, D_hat, U,       \
-                           (const u4v *)img, lgit, nzmask, colsum, DV, n, m, K, ngt, per);                                  \
+                           (const u4v *)img, lgit, mpad, nztiles, colsum, DV, n, m, K, ngt, per);                           \
     } while (0)
     ORIANA_ZI_FOR_CFG(kc, tl, ORIANA_ZI_CALL);
 #undef ORIANA_ZI_CALL

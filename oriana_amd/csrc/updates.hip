@@ -143,6 +143,7 @@ struct GuVecArgs {
     int Kp, nslab;
     int64_t slab_row0;
     float *FUn, *mu_out, *upart;
+    double *a2row;      // [r6] FIN, a2 == NULL: the K rate values every row shares (gap.py:98: alpha2 + sum_j V_hat), written once
 };
 
 template <int VEC> struct VecF;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
                 }
                 st_f32<VEC>(A.Zfin + idx, z);
                 st_f64<VEC>(A.a1 + idx, s1);
-                st_f64<VEC>(A.a2 + idx, s2);
+                if (A.a2) st_f64<VEC>(A.a2 + idx, s2);
                 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
                     el[v] = gamma_meanlog_f32_lg(s1[v], lg2c[v]);
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
                 sE[v] += e[v];
                 sL[v] += (double)el[v];
             }
-            st_f64<VEC>(A.E + idx, e);
+            if (A.E) st_f64<VEC>(A.E + idx, e);
             st_f32<VEC>(A.Elog + idx, el);
         }
         if (prep) {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
         if (A.colsum_E) atomicAdd(&A.colsum_E[k], tE);
         if (A.colsum_Elog) atomicAdd(&A.colsum_Elog[k], tL);
     }
+    if (FIN && A.a2row && blockIdx.x == 0 && w == 0 && sr == 0 && act) st_f64<VEC>(A.a2row + k0, s2c);
     if (prep && threadIdx.x == 0) {
         float *pp = A.upart + 4 * (size_t)blockIdx.x;
         pp[0] = ((sred[0][0] + sred[0][1]) + sred[0][2]) + sred[0][3];
@@ -493,9 +495,17 @@ template <bool FIN>
 static bool gu_vec_launch(GuVecArgs a, hipStream_t s) {
     const bool wide_ok = aligned_to(a.a1, 16) && aligned_to(a.a2, 16) && aligned_to(a.E, 16) && aligned_to(a.Elog, 16) &&
                          aligned_to(a.Z_in, 16) && aligned_to(a.zmul, 16) && aligned_to(a.rate_mat, 16) && aligned_to(a.rmul, 16) &&
-                         aligned_to(a.Zfin, 16) && aligned_to(a.F, 16) && aligned_to(a.Rs, 16) && aligned_to(a.FUn, 16);
+                         aligned_to(a.Zfin, 16) && aligned_to(a.F, 16) && aligned_to(a.Rs, 16) && aligned_to(a.FUn, 16) &&
+                         aligned_to(a.a2row, 16);
     int vec, lpr;
     if (!gu_vec_cfg(a.K, wide_ok, &vec, &lpr)) return false;
+    if (a.FUn) {
+        // The caller sized `upart` with oriana_gamma_update_prep_blocks, which assumes the aligned (wide) configuration: a
+        // pointer that is not 16-byte aligned would drop to a narrower VEC, a smaller rows-per-block and MORE blocks than
+        // upart has room for.  Refuse instead (the entry returns ORIANA_EINVAL).
+        int v2, l2;
+        if (!gu_vec_cfg(a.K, true, &v2, &l2) || v2 != vec || l2 != lpr) return false;
+    }
     a.rpb = gu_vec_rpb(a.r, lpr);
     const int64_t nblk = (a.r + a.rpb - 1) / a.rpb;
     if (vec == 4) gu_vec_launch_lpr<FIN, 4>(a, lpr, nblk, s);
@@ -539,7 +549,7 @@ extern "C" int oriana_gamma_update_prep(double *a1, double *a2, double *E, float
     if (FU_next && (!mu_out || !upart || oriana_kpad(K) == 0)) return ORIANA_EINVAL;
     if (!gu_scalar_forced() && (FU_next || !gu_small(r, K))) {
         GuVecArgs a = {a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, Z, zmul, rate_vec, rate_mat, rmul, r, (int)K, 0,
-                       nullptr, nullptr, nullptr, nullptr, (int)oriana_kpad(K), 1, 0, FU_next, mu_out, upart};
+                       nullptr, nullptr, nullptr, nullptr, (int)oriana_kpad(K), 1, 0, FU_next, mu_out, upart, nullptr};
         if (gu_vec_launch<false>(a, (hipStream_t)stream)) { ORIANA_LAUNCH_CHECK(); return 0; }
     }
     if (FU_next) return ORIANA_EINVAL;                 // (callers ask oriana_gamma_update_prep_blocks first)
@@ -581,7 +591,7 @@ extern "C" int oriana_gamma_update_finalize_prep(double *a1, double *a2, double 
     if (FU_next && (!mu_out || !upart)) return ORIANA_EINVAL;
     if (!gu_scalar_forced() && (FU_next || !gu_small(r, K))) {
         GuVecArgs a = {a1, a2, E, Elog, colsum_E, colsum_Elog, prior1, prior2, nullptr, nullptr, rate_vec, nullptr, nullptr, r, (int)K, 0,
-                       Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0, FU_next, mu_out, upart};
+                       Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0, FU_next, mu_out, upart, nullptr};
         if (gu_vec_launch<true>(a, (hipStream_t)stream)) { ORIANA_LAUNCH_CHECK(); return 0; }
     }
     if (FU_next) return ORIANA_EINVAL;
@@ -598,6 +608,29 @@ extern "C" int oriana_gamma_update_finalize_prep(double *a1, double *a2, double 
         hipLaunchKernelGGL((k_gamma_update<true, 256>), dim3((unsigned)nblk), block, 0, (hipStream_t)stream, a1, a2, E, Elog,
                            colsum_E, colsum_Elog, prior1, prior2, (const float *)nullptr, (const float *)nullptr, rate_vec,
                            (const double *)nullptr, (const float *)nullptr, r, (int)K, rpb, Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
+// [r6] pCMF's cell side without the two matrices nobody reads inside a sweep (gap.py:98, 101): a2 is the same K numbers in
+// every row (alpha2 + sum_j V_hat) -- they go to a2_row[K] once -- and U_hat = a1 / a2 is not stored (its column sums still
+// are summed here).  1.6 of the 4.8 GB the launch moves at configs[3].  The caller (models/gap.py) evaluates both on access.
+// ORIANA_EKRANGE: no vector configuration for this K / these pointers -- the caller takes oriana_gamma_update_finalize_prep.
+extern "C" int oriana_gamma_update_finalize_lazy(double *a1, double *a2_row, float *Elog, double *colsum_E, double *colsum_Elog,
+                                                 const double *prior1, const double *prior2, float *Z, const float *F,
+                                                 const float *R, int64_t nslab, int64_t slab_row0, const int32_t *row_index,
+                                                 const double *rate_vec, int64_t r, int64_t K, float *FU_next, float *mu_out,
+                                                 float *upart, void *stream) {
+    if (r < 0 || K <= 0 || nslab < 1 || nslab > 65535 || slab_row0 < 0) return ORIANA_EINVAL;
+    const int64_t Kp = oriana_kpad(K);
+    if (K > 128 * GU_MAXCOLS_PER_THREAD || Kp == 0) return ORIANA_EKRANGE;
+    if (!a1 || !a2_row || !Elog || !Z || !F || !R || !prior1 || !prior2 || !rate_vec) return ORIANA_EINVAL;
+    if (FU_next && (!mu_out || !upart)) return ORIANA_EINVAL;
+    if (r == 0) return ORIANA_EKRANGE;                 // (nothing would write a2_row)
+    if (gu_scalar_forced() || (!FU_next && gu_small(r, K))) return ORIANA_EKRANGE;     // (launch-bound sizes: the scalar kernel)
+    GuVecArgs a = {a1, nullptr, nullptr, Elog, colsum_E, colsum_Elog, prior1, prior2, nullptr, nullptr, rate_vec, nullptr, nullptr, r, (int)K, 0,
+                   Z, F, R, row_index, (int)Kp, (int)nslab, slab_row0, FU_next, mu_out, upart, a2_row};
+    if (!gu_vec_launch<true>(a, (hipStream_t)stream)) return ORIANA_EKRANGE;
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

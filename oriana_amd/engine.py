@@ -627,6 +627,21 @@ class _NoSpan:
         return False
 
 
+def nzmask_tiles(mask, n, m):
+    """The per-lane non-zero flags of csrc/dense_zi.hip (oriana_nzmask_tiles) from the oriana_nzmask_f32 words of an (n, m)
+    matrix: built once per count matrix, handed to dropout_sweep."""
+    words = int(_lib.load().oriana_nzmask_tiles_words(n, m))
+    tiles = torch.zeros(max(words, 4), dtype=torch.int32, device=mask.device)
+    call('oriana_nzmask_tiles', ptr(tiles), ptr(mask), n, m, stream_ptr())
+    return tiles
+
+
+def dropout_sweep(D, U, V, pi, mask, tiles, colsum, V_next, DV_next, scratch, arithmetic, n, m, K):
+    """oriana_dropout_sweep_fused_tiles (zigap.py:130-136 + the next sweep's zigap.py:116) on device tensors; None -> NULL."""
+    call('oriana_dropout_sweep_fused_tiles', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(tiles), ptr(colsum), ptr(V_next),
+         ptr(DV_next), ptr(scratch), int(arithmetic), n, m, K, stream_ptr())
+
+
 def _span(ws, name):
     t = getattr(ws, 'timer', None)
     return t.span(name) if t is not None else _NoSpan()

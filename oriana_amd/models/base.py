@@ -335,21 +335,37 @@ class FactorModel:
             return (None, None, None)
         return self._ws.prep_outputs(packed_rows) or (None, None, None)
 
-    def _gamma_side_finalize(self, side, Z, F, R, row_index, rate_vec, sums, nslab=1, slab_row0=0):
+    def _gamma_side_finalize(self, side, Z, F, R, row_index, rate_vec, sums, nslab=1, slab_row0=0, a2_row=None):
         """pCMF: Z += F * R (the last step of the responsibility pass, packed rows scattered through `row_index`) and the
-        Gamma update of that side in one launch (oriana_gamma_update_finalize).  `sums` (2, K) must be zero on entry."""
+        Gamma update of that side in one launch (oriana_gamma_update_finalize).  `sums` (2, K) must be zero on entry.
+        `a2_row` (cell side, [r6]): the rate matrix a2 and the mean U_hat are NOT stored -- the K rate values go to a2_row
+        (oriana_gamma_update_finalize_lazy); returns True when that form ran, False when the full form did."""
         if side == 'v':
             self._touch()
+        prep = self._prep_outputs(side, packed_rows=True)
+        if a2_row is not None:
+            assert side == 'u'
+            from .. import _lib
+            rc = _lib.load().oriana_gamma_update_finalize_lazy(
+                ptr(self.a1.tensor), ptr(a2_row), ptr(self._log_U_hat), ptr(sums[0]), ptr(sums[1]), ptr(self.alpha1.tensor),
+                ptr(self.alpha2.tensor), ptr(Z), ptr(F), ptr(R), int(nslab), int(slab_row0), ptr(row_index), ptr(rate_vec), self.n,
+                self.k, ptr(prep[0]), ptr(prep[1]), ptr(prep[2]), stream_ptr())
+            if rc == 0:
+                if prep[0] is not None:
+                    self._ws.fu_pending, self._ws.fu_source = True, self._log_U_hat.data_ptr()
+                return True
+            if rc != -2:                    # ORIANA_EKRANGE: no vector kernel for this K -- the full form below
+                raise OrianaHipError('oriana_gamma_update_finalize_lazy failed with code %d' % rc)
         if side == 'u':
             s1, s2, E, Elog, p1, p2, r = self.a1, self.a2, self._U_hat, self._log_U_hat, self.alpha1, self.alpha2, self.n
         else:
             s1, s2, E, Elog, p1, p2, r = self.b1, self.b2, self._V_hat, self._log_V_hat, self.beta1, self.beta2, self.m
-        prep = self._prep_outputs(side, packed_rows=True)
         call('oriana_gamma_update_finalize_prep', ptr(s1.tensor), ptr(s2.tensor), ptr(E), ptr(Elog), ptr(sums[0]), ptr(sums[1]),
              ptr(p1.tensor), ptr(p2.tensor), ptr(Z), ptr(F), ptr(R), int(nslab), int(slab_row0), ptr(row_index), ptr(rate_vec), r,
              self.k, ptr(prep[0]), ptr(prep[1]), ptr(prep[2]), stream_ptr())
         if prep[0] is not None:
             self._ws.fu_pending, self._ws.fu_source = True, Elog.data_ptr()
+        return False
 
     def _mstep_side(self, side):
         if side == 'u':

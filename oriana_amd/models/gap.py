@@ -1,5 +1,9 @@
 # -*- coding: utf-8 -*-
 """pCMF = Gamma-Poisson factor model (reference oriana/models/gap.py:14-135)."""
+import os
+
+import torch
+
 from .. import engine
 from .base import FactorModel
 
@@ -37,8 +41,13 @@ class GaP(FactorModel):
         engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='rows', finalize_rows=False,
                       clear=(self._sumU, self._accV) + ((self._Zj_o,) if packed else ()), zj_packed=packed)
         # U_q: a1 = alpha1 + Z_i ; a2 = alpha2 + sum_j V_hat (OLD V_hat)                gap.py:97-102
-        self._gamma_side_finalize('u', self._Zi, ws.FU, ws.R, ct.row_perm, self._sumV[0], self._sumU, nslab=ws.row_gene_splits,
-                                  slab_row0=ws.row_slab_row0)
+        lazy = self._gamma_side_finalize('u', self._Zi, ws.FU, ws.R, ct.row_perm, self._sumV[0], self._sumU,
+                                         nslab=ws.row_gene_splits, slab_row0=ws.row_slab_row0,
+                                         a2_row=self._a2_row if self._lazy_ok else None)
+        if lazy:
+            self._u_on_access()
+        else:
+            self._lazy_ok = False            # (no vector kernel for this K / a launch-bound size: decided once per model)
         self._exchange_start()                  # sum_i U_hat | sum_i log U_hat (float64): reduced under the column pass
         engine.zq_gap(ws, self._Zi, self._Zj, self._log_U_hat, self._log_V_hat, phase='cols', finalize_cols=not fold_cols,
                       zj_packed=packed,
@@ -54,8 +63,45 @@ class GaP(FactorModel):
             self._gamma_side('v', self._Zj, rate_vec=self._sumU[0], sums_arg=self._accV, zero=False)
         self._v_sums_in_acc = True
 
+    # ---- [r6] a2 and U_hat of the cell side are evaluated on access ---------------------------------------------------------
+    # Inside a sweep nothing reads them: a2[i, :] = alpha2 + sum_j V_hat is the same K numbers for every cell (gap.py:98) and
+    # U_hat = a1 / a2 (gap.py:101) enters the sweep only through its column sums, which the update kernel forms itself.  The
+    # kernel therefore writes the K rate values once (_a2_row) and model.a2 / model.U_hat / factors() / state() / save()
+    # materialise the (n, K) float64 matrices when somebody asks -- a broadcast and a float64 division, bit for bit what the
+    # kernel would have stored.  1.6 of the 4.8 GB of the cell-side update at configs[3] (ORIANA_LAZY_U=0: stored every sweep).
+    _u_stale = False
+    _U_buf = None
+    _a2_row = None
+    _lazy_ok = True
+
+    @property
+    def _U_hat(self):
+        if self._u_stale:
+            torch.div(self.a1.tensor, self._a2_row, out=self._U_buf)           # Gamma._mean, gamma.py:37-46
+            self._u_stale = False
+        return self._U_buf
+
+    @_U_hat.setter
+    def _U_hat(self, t):
+        self._U_buf, self._u_stale = t, False
+
+    def _u_on_access(self):
+        n, K = self.n, self.k
+        row = self._a2_row
+        self.a2.defer(lambda: row.clone().expand(n, K).contiguous())
+        self._u_stale = True
+
+    def step(self):
+        FactorModel.step(self)
+        if self._graph is not None and self._a2_row is not None and self._lazy_ok:
+            self._u_on_access()              # (a replayed graph ran the kernel again: what was materialised is stale)
+
     def _init_extra(self):
-        import torch
+        if os.environ.get('ORIANA_LAZY_U', '1') != '0':
+            from ..parameters import LazyParameter
+            n, K, dev = self.n, self.k, self.device
+            self._a2_row = torch.ones(K, dtype=torch.float64, device=dev)
+            self.a2 = LazyParameter((n, K), dev, lambda: torch.ones(n, K, dtype=torch.float64, device=dev))   # gap.py:43 (ones)
         if self.sharded and self._ws.Kp == self.k:
             # the gene-side update of the packed exchange: Z in the caller's gene order (cleared by the factor preparation's
             # launch every sweep) and the all-ones factor of  Z[o] = 1 * Zx[p]

@@ -54,6 +54,10 @@ class _ZIMixin:
         # bit mask of X != 0 (constant): lets the D update apply p_d[X != 0] = 1 - 1e-10 in its own pass
         self._nzmask = torch.zeros(((n + 31) // 32) * max(mp, 1), dtype=torch.int32, device=dev)
         call('oriana_nzmask_f32', ptr(self._nzmask), ptr(self._Dp), n, mp, stream_ptr())
+        # [r6] the same mask as per-lane flags for the K = 33 .. 100 D-update kernel (csrc/dense_zi.hip)
+        from .. import _lib
+        self._nztiles = torch.zeros(max(int(_lib.load().oriana_nzmask_tiles_words(n, mp)), 4), dtype=torch.int32, device=dev)
+        call('oriana_nzmask_tiles', ptr(self._nztiles), ptr(self._nzmask), n, mp, stream_ptr())
         self._pd_sum_fresh = False
         # non-zero counts per gene (local rows): the float32 sweep kernel counts p_d = float32(1 - 1e-10) = 1 at the non-zeros;
         # the M-step takes the 1e-10 per entry back, as the reference's float64 mean has it (zigap.py:135, 158) -- a gene
@@ -66,7 +70,6 @@ class _ZIMixin:
         self._fast_dense = self.k <= 128 and os.environ.get('ORIANA_ZI_EXACT', '0') != '1'
         self._DV_next = None
         self.n_kept_products = 0          # sweeps whose D_hat V came from the previous sweep's D update
-        from .. import _lib
         self._lg_scratch = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(mp, self.k)), dtype=torch.float32, device=dev)
         self._dt_scratch = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, self.k)), dtype=torch.float32, device=dev)
         # how the float32 products are evaluated (include/oriana_hip.h): 1 = three-way bf16 splits on the bf16 matrix
@@ -160,9 +163,9 @@ class _ZIMixin:
                 if V_next is not None:
                     DV = torch.zeros(self.n, self.k, dtype=torch.float64, device=self.device)
                     V_next = Vp if V_next is V_for_d else self._padG(V_next, 'Vn')
-                call('oriana_dropout_sweep_fused', ptr(self._Dp), ptr(self._U_hat), ptr(Vp), ptr(pip),
-                     ptr(self._nzmask), ptr(self._pd_sum_p), ptr(V_next), ptr(DV), ptr(self._lg_scratch), self._matrix_arith,
-                     self.n, self._mp, self.k, stream_ptr())
+                call('oriana_dropout_sweep_fused_tiles', ptr(self._Dp), ptr(self._U_hat), ptr(Vp), ptr(pip),
+                     ptr(self._nzmask), ptr(self._nztiles), ptr(self._pd_sum_p), ptr(V_next), ptr(DV), ptr(self._lg_scratch),
+                     self._matrix_arith, self.n, self._mp, self.k, stream_ptr())
                 self._pd_sum.sub_(self._nnz_gene, alpha=1e-10)      # the non-zeros are 1 - 1e-10 each, not 1
             else:
                 DV = None

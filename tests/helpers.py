@@ -118,3 +118,18 @@ def assert_state_close(got, ref, rtol=RTOL, keys=None, what='', exact=None):
         if k == 'p_d':
             assert np.array_equal(np.asarray(got[k]) == 1. - 1e-10, np.asarray(ref[k]) == 1. - 1e-10), \
                 '%s p_d: (1 - 1e-10) mask differs' % what
+
+
+def dropout_sweep(D, U, V, pi, mask, cs, Vn, DV, scratch, arithmetic, n, m, K):
+    """oriana_dropout_sweep_fused_tiles with the per-lane flags built from `mask` (oriana_nzmask_f32 layout; None: no mask,
+    which is the round-2 entry oriana_dropout_sweep_fused)."""
+    import torch
+    from oriana_amd import _lib
+    from oriana_amd._lib import call, ptr, stream_ptr
+    tiles = None
+    if mask is not None:
+        tiles = torch.zeros(max(int(_lib.load().oriana_nzmask_tiles_words(n, m)), 4), dtype=torch.int32, device=mask.device)
+        call('oriana_nzmask_tiles', ptr(tiles), ptr(mask), n, m, stream_ptr())
+    call('oriana_dropout_sweep_fused_tiles', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(tiles), ptr(cs), ptr(Vn), ptr(DV),
+         ptr(scratch), arithmetic, n, m, K, stream_ptr())
+    return tiles

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden_files, load_golden, err_colrel
+from helpers import golden_files, load_golden, err_colrel, dropout_sweep
 
 pytestmark = pytest.mark.gpu
 
@@ -637,8 +637,7 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next, arithmetic):
     cs1 = torch.zeros(m, dtype=torch.float64, device='cuda')
     DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
     lgs = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
-    call('oriana_dropout_sweep_fused', ptr(D1), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs1),
-         ptr(Vn) if with_next else None, ptr(DV) if with_next else None, ptr(lgs), arithmetic, n, m, K, stream_ptr())
+    dropout_sweep(D1, U, V, pi, mask, cs1, Vn if with_next else None, DV if with_next else None, lgs, arithmetic, n, m, K)
     D2 = torch.empty_like(D1)
     cs2 = torch.zeros_like(cs1)
     call('oriana_dropout_update_fused', None, ptr(D2), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs2), n, m, K, stream_ptr())
@@ -683,8 +682,9 @@ def test_dense_sweep_entries_wide_dynamic_range(arithmetic):
     cs = torch.zeros(m, dtype=torch.float64, device='cuda')
     DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
     scr = torch.zeros(int(_lib.load().oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
-    call('oriana_dropout_sweep_fused', ptr(D1), ptr(U), ptr(V), ptr(pi), None, ptr(cs), ptr(Vn), ptr(DV), ptr(scr), arithmetic,
-         n, m, K, stream_ptr())
+    # (a mask of zeros: without the per-lane flags the K = 33 .. 100 kernel of csrc/dense_zi.hip would not run)
+    zmask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device='cuda')
+    dropout_sweep(D1, U, V, pi, zmask, cs, Vn, DV, scr, arithmetic, n, m, K)
     call('oriana_dropout_update_fused', None, ptr(D2), ptr(U), ptr(V), ptr(pi), None, None, n, m, K, stream_ptr())
     torch.cuda.synchronize()
     np.testing.assert_allclose(D1.cpu().numpy(), D2.cpu().numpy(), rtol=2e-5, atol=3e-7)
@@ -810,8 +810,7 @@ def test_dense_zi_kernels_decline_unaligned_buffers():
         assert (D.data_ptr() % 16 == 0) == (shift == 0)
         cs = torch.zeros(m, dtype=torch.float64, device='cuda')
         DV = torch.zeros(n, K, dtype=torch.float64, device='cuda')
-        call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(DV), ptr(lgs), 1,
-             n, m, K, stream_ptr())
+        dropout_sweep(D, U, V, pi, mask, cs, V, DV, lgs, 1, n, m, K)
         DtU = torch.zeros(m, K, dtype=torch.float64, device='cuda')
         call('oriana_dense_t_times_factor_f32', ptr(DtU), ptr(D), ptr(U), ptr(dts), 1, n, m, K, stream_ptr())
         torch.cuda.synchronize()

@@ -271,6 +271,147 @@ def test_oracle_agreement_multi_tile(name):
         assert_state_close(G.state(), O.state(), what='%s sweep %d' % (name, it), exact=E.state() if E is not None else None)
 
 
+def _plan_rows_for(model, cus):
+    """Re-plan the row split of the model's workspace for a chip of `cus` compute units (oriana_row_pass_plan_cus -- the
+    function that plans for the device's own count): a matrix of ~40 row blocks then gets what 1M cells get on 256 CUs, whole
+    row blocks for the full rounds and gene ranges of equal cost for the blocks of the last, partly filled round."""
+    import ctypes
+    from oriana_amd import _lib
+    from oriana_amd._lib import call
+    ws, ct = model._ws, model.counts
+    sp = _lib.OrianaRowSplit()
+    cost = getattr(ct, 'gene_tile_cost', None)
+    call('oriana_row_pass_plan_cus', ct.sparse_struct, int(model.k), cost.ctypes.data if cost is not None else None, int(cus),
+         ctypes.byref(sp))
+    assert sp.nfull > 0 and 1 < sp.parts <= 8, (sp.nfull, sp.parts)
+    ws.set_row_split(sp.nfull, sp.parts, [sp.edge[i] for i in range(sp.parts + 1)] if sp.edge[0] >= 0 else None)
+    return int(sp.nfull), int(sp.parts)
+
+
+def _benchmark_like_counts(rng, n, m, n_dense, d_dense, d_sparse):
+    """(n, m) counts with `n_dense` genes expressed in d_dense of the cells (scattered over the gene axis) and the rest in
+    d_sparse: 3-4 % non-zeros overall, so that a zero-skipping oracle sweep takes seconds."""
+    dens = np.full(m, d_sparse, dtype=np.float32)
+    dens[rng.permutation(m)[:n_dense]] = d_dense
+    X = rng.integers(1, 9, size=(n, m), dtype=np.int8)
+    X *= (rng.random((n, m), dtype=np.float32) < dens[None, :])
+    return X.astype(np.int64)
+
+
+def test_headline_kernels_whole_sweeps_against_the_oracle():
+    """The kernel combination bench.py's headline line measures (configs[3]: pCMF, K = 100), as whole sweeps against
+    OracleGaP -- hybrid layout (dense genes on the bf16 matrix cores + sliced genes on k_row_pass_k100 / k_col_pass2), the row
+    blocks of the last round of the chip split into gene ranges (slabs of R), k_gamma_update_vec<FIN, 4, 32> on both sides
+    (>= 2^20 elements each) with the NEXT sweep's factor preparation folded into the cell side, the K = 100 M-step.  Two
+    consecutive sweeps: the second one consumes the FU, row maxima and statistics the first one prepared.  Full state at 1e-5
+    + the 1e-15 clamp patterns (gap.py:82-129).  The oracle runs its loop nest with the zero counts skipped (bit-identical:
+    tests/test_oracle.py): ~4 s per sweep instead of ~25."""
+    import oriana_amd.models as Mo
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(2026)
+    n, m, K = 10561, 10530, 100                       # ragged: 42 row blocks (the last one 65 rows), 330 gene tiles of 32 (+ 2 genes)
+    assert n * K >= 1 << 20 and m * K >= 1 << 20
+    X = _benchmark_like_counts(rng, n, m, 96, 0.3, 0.03)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    G = Mo.GaP(X, k=K, init=(a1, b1), dense_density=0.2)
+    ct, ws = G.counts, G._ws
+    assert ct.gd >= 64 and ct.ms > 0 and ct.gd % 32 == 0                      # dense block AND sliced genes
+    assert ws.prep_blocks > 0                                                 # the folded preparation engages by size
+    nfull, parts = _plan_rows_for(G, 16)                                      # 42 row blocks on "16 CUs": 2 full rounds + 10 split blocks
+    assert ws.row_gene_splits == parts and ws.row_slab_row0 == nfull * 256
+    assert ws.dense_tail(parts)[1] == parts                                   # the dense row kernel follows the same split
+    O = co.OracleGaP(X, K, a1, b1)
+    O.skip_zeros = True
+    assert_state_close(G.state(), O.state(), what='init')
+    for it in range(2):
+        O.load_state(G.state())                       # (the oracle restarts from the HIP state; the HIP model runs on undisturbed)
+        G.step(); O.step()
+        assert ws.fu_pending, 'the cell-side update did not prepare the next sweep\'s factor'
+        assert_state_close(G.state(), O.state(), what='K=100 hybrid sweep %d' % it)
+    assert int(ws.tile_flag.sum().item()) == 0                                # nothing went down the slow path: the fast kernels were judged
+
+
+def test_lazy_cell_side_matrices_match_the_stored_ones(monkeypatch, tmp_path):
+    """[r6] pCMF keeps a2 (gap.py:98: the same K numbers in every row) and U_hat = a1 / a2 (gap.py:101) of the cell side OUT of
+    the sweep's stores (oriana_gamma_update_finalize_lazy) and evaluates them on access: model.a2[:], model.U_hat, factors(),
+    state(), save() / restore() and a replayed graph give bit for bit what the storing form (ORIANA_LAZY_U=0) gives."""
+    import oriana_amd.models as Mo
+    rng = np.random.default_rng(77)
+    n, m, K = 10700, 300, 100                          # n K >= 2^20: the vector kernel (and with it the lazy form) engages
+    X = (rng.poisson(3.0, size=(n, m)) * (rng.random((n, m)) < 0.1)).astype(np.int64)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    monkeypatch.setenv('ORIANA_LAZY_U', '0')
+    A = Mo.GaP(X, k=K, init=(a1, b1))
+    monkeypatch.setenv('ORIANA_LAZY_U', '1')
+    B = Mo.GaP(X, k=K, init=(a1, b1))
+    assert A._a2_row is None and B._a2_row is not None
+    for k, v in A.state().items():
+        assert np.array_equal(v, B.state()[k]), 'init ' + k
+    for it in range(2):
+        A.step(); B.step()
+        assert B._lazy_ok and B._u_stale and not B.a2.materialised           # nothing was stored
+        assert np.array_equal(A.a2[:], B.a2[:]) and np.array_equal(A.U_hat, B.U_hat)
+        assert B.a2[3:5, 7].shape == (2,) and np.array_equal(A.a2[3:5, 7], B.a2[3:5, 7])
+        Ua, Va = A.factors(); Ub, Vb = B.factors()
+        assert np.array_equal(Ua, Ub) and np.array_equal(Va, Vb)
+        sa, sb = A.state(), B.state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), 'sweep %d %s' % (it, k)
+    ck = str(tmp_path / 'lazy.npz')
+    B.save(ck)
+    C = Mo.GaP(X, k=K, init=(a1, b1))
+    C.restore(ck)
+    A.step(); B.step(); C.step()
+    sa, sb, sc = A.state(), B.state(), C.state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+        assert err_colrel(sc[k], sb[k]) < 2e-6, k      # (a restored run recomputes the column sums from the stored matrices)
+    # a write from outside lands in the materialised matrix and is what the next expectation update reads (parameters.py:24-25)
+    B.a2[0, 0] = 123.0
+    assert B.a2[0, 0] == 123.0
+    B.update_expectations()
+    assert abs(B.U_hat[0, 0] - B.a1[0, 0] / 123.0) < 1e-15 * abs(B.U_hat[0, 0]) + 1e-300
+    # replayed graph: every replay runs the lazy kernel again, so what was materialised before is stale afterwards
+    D = Mo.GaP(X, k=K, init=(a1, b1))
+    E = Mo.GaP(X, k=K, init=(a1, b1))
+    D.capture_graph()                                  # (runs sweep 1 eagerly; the captured sweep has not run yet)
+    E.step()
+    u1 = D.U_hat                                       # materialised now ...
+    D.step(); E.step()                                 # ... and stale after the replay
+    assert not np.array_equal(D.U_hat, u1)
+    np.testing.assert_allclose(D.U_hat, E.U_hat, rtol=1e-5)
+    np.testing.assert_allclose(D.a2[:], E.a2[:], rtol=1e-5)
+    assert np.array_equal(D.U_hat, D.a1[:] / D.a2[:])
+
+
+def test_config5_kernels_whole_sweeps_against_the_oracle():
+    """The same for configs[4]: sparse pCMF, K = 64, sliced layout -- the fused two-image k64 row pass and the dual column
+    pass, split last round, k_gamma_update_vec on both sides (sparse_gap.py:99-148).  Gamma parameters and expectations at
+    1e-5 + clamp patterns; S_tilde bit-exact; the sparsity posterior against the oracle's own float32 arithmetic at the
+    documented bound of helpers.KEY_RTOL."""
+    import oriana_amd.models as Mo
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(2027)
+    n, m, K = 16421, 16390, 64
+    assert n * K >= 1 << 20 and m * K >= 1 << 20
+    X = _benchmark_like_counts(rng, n, m, 64, 0.25, 0.025)
+    a1 = rng.gamma(1.0, size=(n, K)); b1 = rng.gamma(1.0, size=(m, K))
+    G = Mo.SparseGaP(X, k=K, init=(a1, b1), dense_density=None)
+    ws = G._ws
+    assert G.counts.gd == 0 and ws.prep_blocks > 0
+    _plan_rows_for(G, 16)
+    O = co.OracleSparseGaP(X, K, a1, b1)
+    O.skip_zeros = True
+    assert_state_close(G.state(), O.state(), what='init')
+    for it in range(2):
+        O.load_state(G.state())
+        St = (O.p_s > O.tau).astype(np.float32)                               # sparse_gap.py:113, from the state both start from
+        G.step(); O.step()
+        assert ws.fu_pending
+        assert np.array_equal(G._S_tilde.cpu().numpy(), St)
+        assert_state_close(G.state(), O.state(), what='K=64 sparse sweep %d' % it)
+
+
 @pytest.mark.parametrize('K', [33, 50, 68, 84, 100])
 @pytest.mark.parametrize('m', [272, 271, 270, 269])
 @pytest.mark.parametrize('name', ['ZIGaP', 'SparseZIGaP'])
@@ -814,8 +955,8 @@ def test_config3_zi_slab_against_float64_oracle():
     psum = torch.zeros(m, dtype=torch.float64, device='cuda')
     DV = torch.zeros(sl, K, dtype=torch.float64, device='cuda')
     lg = torch.zeros(int(lib.oriana_dropout_sweep_scratch_floats(m, K)), dtype=torch.float32, device='cuda')
-    call('oriana_dropout_sweep_fused', ptr(D_new), ptr(U64), ptr(V64), ptr(model.pi_d.tensor), ptr(nzm), ptr(psum), ptr(V64),
-         ptr(DV), ptr(lg), 1, sl, m, K, stream_ptr())
+    from helpers import dropout_sweep
+    dropout_sweep(D_new, U64, V64, model.pi_d.tensor, nzm, psum, V64, DV, lg, 1, sl, m, K)
     DtU = torch.zeros(m, K, dtype=torch.float64, device='cuda')
     scr = torch.zeros(int(lib.oriana_dense_t_scratch_floats(sl, K)), dtype=torch.float32, device='cuda')
     call('oriana_dense_t_times_factor_f32', ptr(DtU), ptr(D_new), ptr(U64), ptr(scr), 1, sl, m, K, stream_ptr())

@@ -184,3 +184,45 @@ def test_openmp_variant_agrees_with_single_thread():
         pytest.skip('OpenMP build unavailable: %r' % (e,))
     assert np.array_equal(Zi, Zi2)
     assert err_colrel(Zj2, Zj) < 1e-6
+
+
+@pytest.mark.parametrize('path', golden_files('gap_*.npz') + golden_files('sparsegap_*.npz'), ids=os.path.basename)
+def test_zero_skipping_nests_are_bit_identical_on_the_goldens(path):
+    """oracle/zq_kernels.c zq_gap_nz / zq_sparse_gap_nz (the nests with the zero counts skipped, which the -m gpu sweep
+    tests at benchmark-sized K use) against the pinned full nests, on the reference's own kernel inputs of every pCMF /
+    sparse pCMF golden -- including the NMF starts, whose exponentials underflow: bit for bit."""
+    g = load_golden(path)
+    M = _model(g)
+    N = _model(g)
+    N.skip_zeros = True
+    for _ in range(3):
+        M.step(); N.step()
+        for a, b in zip(M.last_Z, N.last_Z):
+            if a is not None and (M.sparse or a is not M.last_Z[2]):
+                assert np.array_equal(a, b)
+        sa, sb = M.state(), N.state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_zero_skipping_nests_are_bit_identical_on_random_inputs():
+    rng = np.random.default_rng(11)
+    n, m, K = 157, 203, 100
+    X = (rng.poisson(3.0, size=(n, m)) * (rng.random((n, m)) < 0.1)).astype(np.float32)
+    lu = rng.normal(scale=3.0, size=(n, K)).astype(np.float32)
+    lv = rng.normal(scale=3.0, size=(m, K)).astype(np.float32)
+    lv[5] = -200.0                                         # a gene whose exponentials all underflow: den == 0 -> 1
+    St = (rng.random((m, K)) < 0.7).astype(np.float32)
+    St[7] = 0.0                                            # a gene with no active factor
+    Sh = rng.random((m, K)).astype(np.float32)
+    a = [np.empty((n, K), np.float32), np.empty((m, K), np.float32)]
+    b = [np.empty((n, K), np.float32), np.empty((m, K), np.float32)]
+    co.zq_gap(a[0], a[1], lu, lv, X)
+    co.zq_gap_nz(b[0], b[1], lu, lv, X)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = a + [np.empty((m, K), np.float32)]
+    b = b + [np.empty((m, K), np.float32)]
+    co.zq_sparse_gap(a[0], a[1], a[2], lu, lv, St, Sh, X)
+    co.zq_sparse_gap_nz(b[0], b[1], b[2], lu, lv, St, Sh, X)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

@@ -37,16 +37,26 @@ def timeit(f, reps=5):
 
 st = stream_ptr()
 rows = []
-if K <= 64:
-    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), 1, n, m, K, st))
+# [r6] the sweep entry with the per-lane flags (csrc/dense_zi.hip); a round-5 library (ORIANA_HIP_LIB=...) has the old entry only
+if hasattr(_lib.load(), 'oriana_nzmask_tiles'):
+    from oriana_amd import engine
+    tiles = engine.nzmask_tiles(mask, n, m)
+    def sweep(arith, Vn, DV):
+        call('oriana_dropout_sweep_fused_tiles', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(tiles), ptr(cs), ptr(Vn), ptr(DV),
+             ptr(lgs), arith, n, m, K, st)
+else:
+    def sweep(arith, Vn, DV):
+        call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(Vn), ptr(DV), ptr(lgs), arith, n, m, K, st)
+if K <= 100:
+    t = timeit(lambda: sweep(1, V, o1))
     rows.append(('bf16x3  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K + 31) // 32)) / t / 1e9, 4.0 * n * m / t / 1e9))
-t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V), ptr(o1), ptr(lgs), 0, n, m, K, st))
+t = timeit(lambda: sweep(0, V, o1))
 rows.append(('f32  D update + D V_next (fused)', t, 2.0 * n * m * (K + 32 * ((K + 31) // 32)) / t / 1e9, 4.0 * n * m / t / 1e9))
 if '--shipped-only' not in sys.argv:       # (counter runs: only the two kernels a sweep launches)
-    t = timeit(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), None, None, ptr(lgs), 0, n, m, K, st))
+    t = timeit(lambda: sweep(0, None, None))
     rows.append(('f32  D update alone', t, 2.0 * n * m * K / t / 1e9, 4.0 * n * m / t / 1e9))
 scr = torch.zeros(int(_lib.load().oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device=dev)
-if K <= 64:
+if K <= 100:
     t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), ptr(scr), 1, n, m, K, st))
     rows.append(('bf16x3  D^T U', t, 2.0 * n * m * 32 * ((K + 31) // 32) / t / 1e9, 4.0 * n * m / t / 1e9))
 t = timeit(lambda: call('oriana_dense_t_times_factor_f32', ptr(o2), ptr(D), ptr(U), ptr(scr), 0, n, m, K, st))

@@ -32,6 +32,8 @@ def main():
     mask = torch.zeros(((n + 31) // 32) * m, dtype=torch.int32, device=dev)
     call('oriana_nzmask_f32', ptr(mask), ptr(X), n, m, stream_ptr())
     D = X                                                  # (overwritten by the sweep: the non-zeros stay 1)
+    from oriana_amd import engine
+    tiles = engine.nzmask_tiles(mask, n, m)
     lib = _lib.load()
     for K in [int(a) for a in sys.argv[3:]]:
         U = torch.rand(n, K, dtype=torch.float64, device=dev, generator=g) * 0.2
@@ -44,8 +46,8 @@ def main():
         dts = torch.zeros(int(lib.oriana_dense_t_scratch_floats(n, K)), dtype=torch.float32, device=dev)
         res = []
         for arith, name in ((1, 'bf16x3'), (0, 'f32')):
-            ts = timed(lambda: call('oriana_dropout_sweep_fused', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(cs), ptr(V),
-                                    ptr(DV), ptr(lgs), arith, n, m, K, stream_ptr()))
+            ts = timed(lambda: call('oriana_dropout_sweep_fused_tiles', ptr(D), ptr(U), ptr(V), ptr(pi), ptr(mask), ptr(tiles), ptr(cs),
+                                    ptr(V), ptr(DV), ptr(lgs), arith, n, m, K, stream_ptr()))
             td = timed(lambda: call('oriana_dense_t_times_factor_f32', ptr(out), ptr(D), ptr(U), ptr(dts), arith, n, m, K,
                                     stream_ptr()))
             res.append('%s: D update %.2f ms (%.2f ps/entry), D^T U %.2f ms (%.2f ps/entry)' % (

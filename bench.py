@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide); v_pk_fma_f32 measured: 131 TFLOP/s (tools/ubench/fma_rate.hip)
 LDS_PEAK_GBS = 256 * 256 * 2.4   # 256 CUs x 256 B/clk (ds_read_b128, same guide) x 2.4 GHz = 157 TB/s
+MATRIX_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide: ~2.5 PFLOP/s; never the 2:1-sparsity headline)
 
 WORKLOADS = {
     # name: (model, n_total, m, K, zero_inflation_level, BASELINE.json config)
@@ -219,7 +220,7 @@ def main():
                     f.write(json.dumps(out) + '\n')
             except OSError:
                 pass
-            out['secondary_workloads'] = run_secondaries(('c3_zi', 'c5_sparse', 'c3_zi_nmf'))
+            out['secondary_workloads'] = run_secondaries(('c3_zi', 'c5_sparse', 'c3_zi_nmf', 'c4_eighth_z05'))
         _flush_c_stdio()
         print(json.dumps(out))
         sys.stdout.flush()
@@ -328,8 +329,10 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     marks = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for i in sampled}
     if world > 1 or odist.sharded():
         model._xch.timing = True         # events around every blocking exchange: allreduce_exposed_ms
-    flagged = []                     # (NMF-start workload: slow-path tiles of every sweep -- one host read per sweep)
+    # (NMF-start workload: slow-path tiles of every sweep, summed on the device into one slot per sweep and read AFTER the timed
+    #  region -- a host read per sweep would put a device-to-host round trip into every step of `value`)
     ntiles = counts.nrb * counts.ncb
+    flagged_dev = torch.zeros(max(args.steps, 1), dtype=torch.int64, device=dev) if nmf_start else None
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -342,10 +345,11 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
         else:
             model.step()
         if nmf_start:
-            flagged.append(int(model._ws.tile_flag[:max(ntiles, 1)].sum().item()))
+            flagged_dev[i].copy_(model._ws.tile_flag[:max(ntiles, 1)].sum())
     barrier()
     elapsed = time.perf_counter() - t0
     model._ws.timer = None
+    flagged = [int(v) for v in flagged_dev.tolist()] if nmf_start else []
     exposed_ms = model._xch.exposed_ms() if (world > 1 or odist.sharded()) else None
     model._xch.timing = False
     if world > 1:
@@ -376,6 +380,12 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     useful_tflops = 6.0 * counts.nnz_sparse * K / (resp_ms * 1e-3) / 1e12 if resp_ms > 0 else 0.0
     useful_lds_gbs = 8.0 * counts.nnz_sparse * K / (resp_ms * 1e-3) / 1e9 if resp_ms > 0 else 0.0
     check = float(model.alpha1.tensor.sum().item() + model.beta1.tensor.sum().item())
+    # SURVEY 8(d)'s second regime (z = 0.5, the reference generator's default: ~53 % zeros): the pass is no longer priced by the
+    # bytes of X but by its arithmetic -- the sliced non-zeros on the vector ALUs, the dense block on the bf16 matrix cores (six
+    # cross products of three-way splits per float32 product: 36 K bf16 flops per dense entry for den, R and C)
+    dense_ms = sum(ks.get(k, 0.0) for k in ('dense_row', 'dense_col'))
+    matrix_tflops = 36.0 * K * float(n) * counts.gd / (dense_ms * 1e-3) / 1e12 if dense_ms > 0 else 0.0
+    compute_bound = z >= 0.3
 
     # multi-GPU: per-rank pass times and the time of the sweep's packed all-reduce (measured outside the timed region)
     per_rank = None
@@ -417,6 +427,9 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
     stateless = None
     if rank == 0 and world == 1 and cpu_rows is not None and mname == 'GaP' and not brief:
         stateless = stateless_binding_ms(np, torch, engine, model, gen, m, K, dev)
+    twin = None
+    if rank == 0 and world == 1 and cpu_rows is not None and mname in ('ZIGaP', 'SparseGaP') and not args.workload.endswith('_nmf'):
+        twin = resident_twin_ms(np, torch, engine, model, gen, mname, m, K, dev)
 
     if rank == 0:
         traffic, traffic_src = recorded_traffic(args.workload, world, counts.gd > 0)
@@ -440,7 +453,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                                   'bf16 matrix cores (float32-equivalent: exact three-way splits, six cross products), %d genes sliced'
                                   % (counts.gd, 100.0 * counts.dense_density, 100.0 * counts.dense.nnz / max(counts.nnz, 1), counts.ms))
                                  if counts.gd else 'sliced non-zero layout'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'valu+matrix' if compute_bound else 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          # the same algorithmic bytes over the WHOLE sweep's wall time (updates, launches and gaps included)
                          'frac_step': frac_step,
@@ -466,6 +479,11 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                                   'frac': useful_tflops / VALU_PEAK_TFLOPS},
                          'lds': {'achieved': useful_lds_gbs, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',
                                  'frac': useful_lds_gbs / LDS_PEAK_GBS},
+                         # the dense genes' kernels against the dense bf16 matrix peak (issued flops: six bf16 products per
+                         # float32 product, 3 K products per entry)
+                         'matrix': {'achieved': matrix_tflops, 'peak': MATRIX_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16, issued)',
+                                    'frac': matrix_tflops / MATRIX_BF16_PEAK_TFLOPS,
+                                    'dense_entries': int(n) * int(counts.gd), 'dense_ms': dense_ms},
                          'slot_efficiency': counts.slot_efficiency()},
             'cpu_baseline': cpu,
             'parity_slab': slab,
@@ -516,6 +534,8 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                                'before the dense gene-side kernel, the dense genes\' segment after it')
         if stateless is not None:
             out['stateless_binding'] = stateless
+        if twin is not None:
+            out['resident_binding'] = twin
         if nmf_start:
             settled = sorted(sweep_ms[-5:])[len(sweep_ms[-5:]) // 2]
             out['transient'] = {'what': 'sweeps 0..%d after the reference\'s default start (use_factors=True: NMF factors as initial '
@@ -530,7 +550,7 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                                          'what': 'one-rank process group: every collective of the sharded sweep issued as a self all-reduce'}
         if brief:
             keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'dtype', 'config',
-                    'roofline', 'parity_slab', 'f64_reference_arithmetic_ms', 'cpu_baseline', 'check', 'transient')
+                    'roofline', 'parity_slab', 'f64_reference_arithmetic_ms', 'cpu_baseline', 'check', 'transient', 'resident_binding')
             out = {k: out[k] for k in keep if k in out}
             out['workload'] = workload
     else:
@@ -555,13 +575,18 @@ def recorded_traffic(workload, world, hybrid=False):
     source) and null elsewhere."""
     if world != 1:
         return None, None
-    tag = workload + ('_hybrid' if hybrid else '')
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    # (the NMF start runs the kernels of configs[2] on the same matrix: its settled sweeps move what the c3_zi counter run counted)
+    same_as = {'c3_zi_nmf': 'c3_zi'}
+    tag = same_as.get(workload, workload) + ('_hybrid' if hybrid else '')
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_hbm_%s.json' % (rnd, tag))
         if os.path.exists(path):
             try:
                 with open(path) as f:
-                    return float(json.load(f)['traffic_bytes_per_pass']['total']), 'recorded: profiles/' + os.path.basename(path)
+                    src = 'recorded: profiles/' + os.path.basename(path)
+                    if workload in same_as:
+                        src += ' (the counter run of %s: same matrix, same kernels)' % same_as[workload]
+                    return float(json.load(f)['traffic_bytes_per_pass']['total']), src
             except Exception:
                 return None, None
     return None, None
@@ -619,6 +644,73 @@ def stateless_binding_ms(np, torch, engine, model, gen, m, K, dev, rows=2048):
                     'resident_vs_model_path': res_ms / py_ms if py_ms > 0 else None,
                     'resident_dense_genes': int(info[5]), 'resident_bytes': int(info[8]),
                     'resident_vs_model_path_max_abs_diff_rel': float(max((Zi_r - Zi).abs().max().item(), (Zj_r - Zj).abs().max().item()) / scale)})
+    except Exception as exc:                        # never let the extra figure break the bench line
+        out['resident_error'] = repr(exc)[:300]
+    return out
+
+
+def resident_twin_ms(np, torch, engine, model, gen, mname, m, K, dev, rows=2048):
+    """[r6] The resident C-ABI handle for the nests of the ZI / sparse models: oriana_counts_create_dense_f32
+    once + oriana_counts_declare_unit_dropout, then oriana_zq_zigap_resident (zigap.py:105-112; third output NULL, as the model
+    classes skip it) / oriana_zq_sparse_gap_resident (sparse_gap.py:107-115) per call, beside the same slab through the Python
+    host path of the models (engine.CountTiles + engine.zq), timed the same way.  ms per call on the first `rows` cells."""
+    import ctypes
+    rows = min(rows, gen.n)
+    X = gen.chunk(0, rows).to(torch.float32).contiguous()
+    lu = model._log_U_hat[:rows].contiguous()
+    lv = model._log_V_hat.contiguous()
+    Zi = torch.empty(rows, K, device=dev); Zj = torch.empty(m, K, device=dev); Zl = torch.empty(m, K, device=dev)
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    out = {'rows': rows, 'genes': m, 'K': K}
+    try:
+        lib = engine._lib.load()
+        dd = float(getattr(model.counts, 'dense_density', None) or 0.0) if model.counts.gd else 0.0
+        h = ctypes.c_void_p(None)
+        engine.call('oriana_counts_create_dense_f32', ctypes.addressof(h), engine.ptr(X), rows, m, m, K, dd, engine.stream_ptr())
+        engine.call('oriana_counts_declare_unit_dropout', h, 1)
+        st = engine.stream_ptr()
+        ct = engine.CountTiles.from_dense(X, dev, dense_density=dd or None)
+        ws = engine.ZWorkspace(ct, K)
+        if mname == 'ZIGaP':
+            D = model._Dp[:rows, :m].contiguous()
+            quirk = 1 if model.reference_quirks else 0
+            out['entry'] = 'oriana_zq_zigap_resident (csrc/resident.hip), D_hat == 1 at the non-zero counts declared, third output NULL'
+            res = lambda: engine.call('oriana_zq_zigap_resident', h, engine.ptr(Zi), engine.ptr(Zj), None, engine.ptr(lu), engine.ptr(lv),
+                                      engine.ptr(D), quirk, st)
+            dq = torch.empty(rows, K, dtype=torch.float32, device=dev) if quirk else None
+
+            def py():
+                if quirk:
+                    engine.call('oriana_take_cols_f32', engine.ptr(dq), engine.ptr(D), rows, m, K, engine.stream_ptr())
+                engine.zq(ws, Zi, Zj, None, lu, lv, dq=dq)
+        else:
+            model._threshold()
+            St, Sh = model._S_tilde.contiguous(), model._S_hat.contiguous()
+            out['entry'] = 'oriana_zq_sparse_gap_resident (csrc/resident.hip)'
+            res = lambda: engine.call('oriana_zq_sparse_gap_resident', h, engine.ptr(Zi), engine.ptr(Zj), engine.ptr(Zl), engine.ptr(lu),
+                                      engine.ptr(lv), engine.ptr(St), engine.ptr(Sh), st)
+            py = lambda: engine.zq(ws, Zi, Zj, Zl, lu, lv, S_tilde=St, S_hat=Sh)
+        res_ms = timed(res, 20)
+        r_out = (Zi.clone(), Zj.clone(), Zl.clone())
+        py_ms = timed(py, 20)
+        torch.cuda.synchronize()
+        lib.oriana_counts_destroy(h)
+        scale = float(Zj.abs().max().item()) or 1.0
+        diff = max((r_out[0] - Zi).abs().max().item(), (r_out[1] - Zj).abs().max().item())
+        if mname != 'ZIGaP':
+            diff = max(diff, (r_out[2] - Zl).abs().max().item() / (float(Zl.abs().max().item()) or 1.0) * scale)
+        out.update({'resident_ms_per_call': res_ms, 'model_path_ms_per_call': py_ms,
+                    'resident_vs_model_path': res_ms / py_ms if py_ms > 0 else None,
+                    'resident_vs_model_path_max_abs_diff_rel': float(diff / scale)})
     except Exception as exc:                        # never let the extra figure break the bench line
         out['resident_error'] = repr(exc)[:300]
     return out

@@ -29,6 +29,7 @@ extern "C" {
 #define ORIANA_EINVAL   (-1)   /* bad argument (NULL pointer, negative size, K out of range) */
 #define ORIANA_EKRANGE  (-2)   /* K larger than the largest compiled configuration */
 #define ORIANA_EQUIRK   (-3)   /* reference_quirks needs K <= m (zigap.py:94 reads D_hat[i, k]) */
+#define ORIANA_EUNIT    (-4)   /* a hybrid resident handle serves the ZI nests under oriana_counts_declare_unit_dropout only */
 
 /* 8-byte record of one slot of the row-side stream.  x == 0 marks a padding slot. */
 typedef struct {
@@ -260,6 +261,10 @@ int oriana_col_pass(const oriana_counts *cm, const float *s_cs,
  * Returns ORIANA_EKRANGE when two images do not fit (Kp > 64): call oriana_col_pass twice then. */
 int oriana_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,
                          float *C2, int64_t K, const int32_t *work, int64_t nwork, void *stream);
+/* [r6] Analysis entry, not on the path of a sweep: the same sums with float64 accumulators in a fixed order and one rounding to
+ * float32 at the end (C += f32(sum_i s_ij G_i)): the most a compensated accumulation of the float32 kernels could reach
+ * (tools/parity_report.py: ORIANA_COL_F64=1 routes the per-gene sums of the sparse models' log sums through it). */
+int oriana_col_pass_f64acc(const oriana_counts *cm, const float *s_cs, const float *G, float *C, int64_t K, void *stream);
 /* Deterministic debug mode of the column pass (no counterpart in the reference, which is
  * single-threaded): every work item stores its accumulators in its own slab of `scratch`
  * (oriana_col_pass_det_scratch_bytes(K, nwork) bytes) instead of adding them to C with float atomics, and a
@@ -680,8 +685,21 @@ int oriana_counts_info(const oriana_resident *h, int64_t *info, int64_t len);
 /* GaP.compute_Z_q_expectations (gap.py:67-80) on the resident layout, sliced or hybrid. */
 int oriana_zq_gap_resident(oriana_resident *h, float *Z_hat_i, float *Z_hat_j, const float *log_U_hat, const float *log_V_hat,
                            void *stream);
-/* The three twins (zigap.py:79-95, sparse_gap.py:81-97, sparse_zigap.py:100-116) on a resident SLICED layout (ORIANA_EINVAL for a
- * hybrid handle); D_hat (n, m) is gathered at the stored entries on every call. */
+/* The three twins (zigap.py:79-95, sparse_gap.py:81-97, sparse_zigap.py:100-116) on the resident layout.
+ *
+ * [r6] oriana_counts_declare_unit_dropout(h, 1): the caller declares that every D_hat it will pass is exactly 1 wherever the
+ * count is non-zero -- which holds for every D_hat the reference's own models produce (zigap.py:135 / sparse_zigap.py:168 set
+ * p_d[X != 0] = 1 - 1e-10, Bernoulli.mean casts to float32: bernoulli.py:45; the initial p_d = (X > 0): zigap.py:77).  The
+ * nests then run exactly as oriana_amd's model classes run them: sliced OR hybrid handle, no gather of D_hat (it is read for
+ * the D_hat[i, k] weights of zigap.py:94 only), and for Kp <= 64 the fused kernels -- the S_hat-weighted row sums out of the
+ * two-image row pass, both per-gene sums out of one dual column pass (Kp > 64: den-only row pass + second row product + two
+ * column passes).  oriana_zq_sparse_gap_resident has no D_hat and always runs this way.
+ * Without the declaration (the default) D_hat may hold anything: it is gathered at the stored entries on every call and the
+ * weighted four-kernel form runs, on a SLICED handle only (ORIANA_EUNIT for a hybrid one: the dense-gene kernels carry no
+ * per-entry weights).
+ * The third output (the log sums) may be NULL: the reference's ZIGaP never reads it (zigap.py:105-112) and the model classes
+ * skip it; the sparse models need it (sparse_gap.py:135). */
+int oriana_counts_declare_unit_dropout(oriana_resident *h, int on);
 int oriana_zq_zigap_resident(oriana_resident *h, float *DZ_hat_i, float *DZ_hat_j, float *DZ_exp_logsum_hat,
                              const float *log_U_hat, const float *log_V_hat, const float *D_hat, int reference_quirks, void *stream);
 int oriana_zq_sparse_gap_resident(oriana_resident *h, float *SZ_hat_i, float *Z_hat_j, float *Z_exp_logsum_hat,

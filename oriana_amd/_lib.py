@@ -69,6 +69,7 @@ _SIGS = {
     'oriana_counts_create_dense_f32': (c_int, [_P, _P, _I, _I, _I, _I, c_double, _P]),
     'oriana_counts_create_csr': (c_int, [_P, _P, _P, _P, _I, _I, _I, c_double, _P]),
     'oriana_counts_destroy': (c_int, [_P]),
+    'oriana_counts_declare_unit_dropout': (c_int, [_P, c_int]),
     'oriana_counts_info': (c_int, [_P, _P, _I]),
     'oriana_zq_gap_resident': (c_int, [_P, _P, _P, _P, _P, _P]),
     'oriana_zq_zigap_resident': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P]),
@@ -76,6 +77,7 @@ _SIGS = {
     'oriana_zq_sparse_zigap_resident': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    'oriana_col_pass_f64acc': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P]),
     'oriana_col_pass_det_scratch_bytes': (c_int64, [_I, _I]),
     'oriana_col_pass_det': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P, _P]),
     'oriana_dense_supported': (c_int, [_I]),

@@ -23,8 +23,8 @@
 // D reg v: [m = 8 (v / 4) + 4 (lane >> 5) + v % 4][n = lane & 31].
 #include "common.h"
 #include <type_traits>
-// Compile-time ablation switches for the measurements quoted in DESIGN.md (never set in the shipped build):
-// ORIANA_ABL32_NOSTORE / _NOSIG / _NOTRANS drop one ingredient of k_dropout_sweep.
+// (the ablation switches behind the measurements of DESIGN_HISTORY.md -- ORIANA_ABL32_NOSTORE / _NOSIG / _NOTRANS -- are
+// archived as a patch: tools/experiments/dense_f32_mfma_ablation_switches_r2.diff)
 
 namespace oriana {
 
@@ -227,11 +227,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
             const float2 mt = mts[acc_row(v, h)];
             if ((v & 3) == 0) __builtin_amdgcn_sched_barrier(0);     // four entries at a time: bounded register use
             const float x = mt.x - l0[v];
-#ifdef ORIANA_ABL32_NOSIG
-            float p = x;
-#else
             float p = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-#endif
             if (mt.x == -INFINITY) p = 1e-10f;                   // pi_d <= 0                         zigap.py:133
             if ((__float_as_uint(mt.y) >> c) & 1u) p = 1.0f;     // X != 0: f32(1 - 1e-10) == 1       zigap.py:135
             l0[v] = p;
@@ -240,10 +236,8 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
 #pragma unroll
             for (int v = 0; v < 16; ++v) if (!rowok || acc_row(v, h) >= jrem) l0[v] = 0.f;
         }
-#ifndef ORIANA_ABL32_NOTRANS
 #pragma unroll
         for (int v = 0; v < 16; ++v) T[c * TS + acc_row(v, h)] = l0[v];
-#endif
         __builtin_amdgcn_wave_barrier();
         stage_store(buf ^ 1);
         meta_store(buf ^ 1);
@@ -259,11 +253,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
                 const f4v t = *reinterpret_cast<const f4v *>(T + r * TS + gq);
                 csum += t;
                 const int64_t i = i0w + r;
-#ifdef ORIANA_ABL32_NOSTORE
-                if (D_hat && i < n && t.x == 12345.678f) {
-#else
                 if (D_hat && i < n) {
-#endif
                     float *dst = D_hat + i * m + j0 + gq;
                     if (full) *reinterpret_cast<f4v *>(dst) = t;
                     else {
@@ -895,9 +885,6 @@ __global__ __launch_bounds__(256) void k_split_rows(u4v *__restrict__ img, const
     for (int sp = 0; sp < 3; ++sp) dst[sp * 64] = o[sp];
 }
 
-#ifndef ORIANA_ZI_TILEMAJOR
-#define ORIANA_ZI_TILEMAJOR 0
-#endif
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restrict__ out, const float *__restrict__ D,
                                                                 const u4v *__restrict__ img, int64_t n, int64_t m, int K,
@@ -954,12 +941,7 @@ __global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restri
     // matrix -- one running pointer, eight plain loads per chunk
     auto group = [&](auto fast_tag, int64_t i0, bool more) {
         constexpr bool FAST = decltype(fast_tag)::value;
-#if ORIANA_ZI_TILEMAJOR           // (timing experiment: D_hat as [cell tile][gene tile][32 x 32]; a group of 32 rows = one tile)
-        const int64_t ngt_ = (m + 31) / 32;
-        const float *dp = D + (((i0 + 16 * CH) >> 5) * ngt_ + (jw >> 5)) * 1024 + (8 * h) * 32 + c;
-#else
         const float *dp = D + (i0 + 16 * CH + 8 * h) * m + j;    // (dereferenced on the fast path only)
-#endif
         stage_load(more ? i0 + 16 * CH : i0);                    // (unconditional: the last group is staged again, unread)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -970,13 +952,8 @@ __global__ __launch_bounds__(256, 2) void k_dt_times_factor_b16(double *__restri
             if (FAST) {
                 const float *r = dp;
 #pragma unroll
-#if ORIANA_ZI_TILEMAJOR
-                for (int e = 0; e < 8; ++e) { ring[ch][e] = *r; r += 32; }
-                dp += 16 * 32;
-#else
                 for (int e = 0; e < 8; ++e) { ring[ch][e] = *r; r += m; }
                 dp += 16 * m;
-#endif
             } else {
                 load_checked(ring[ch], i0 + 16 * (ch + CH));
             }

@@ -11,8 +11,8 @@
 //   A[row = lane & 15][k = lane >> 4],  B[k = lane >> 4][col = lane & 15],
 //   D reg r: [row = (lane >> 4) + 4 r][col = lane & 15].
 #include "common.h"
-// Compile-time ablation switches used for the measurements quoted in DESIGN.md section 4 (never set in the
-// shipped build): ORIANA_ABL_NOMFMA / _NOSIG / _NOSTORE / _NOMASK drop one ingredient of k_dropout_fused.
+// (the ablation switches behind the round-1 measurements -- ORIANA_ABL_NOMFMA / _NOSIG / _NOSTORE / _NOMASK -- are archived as
+// a patch: tools/experiments/dense_f32_mfma_ablation_switches_r2.diff)
 
 namespace oriana {
 
@@ -195,12 +195,10 @@ __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p
         t.pi = ok ? pi_d[j] : 0.5;
         t.w0 = 0;
         t.w1 = 0;
-#ifndef ORIANA_ABL_NOMASK
         if (nzmask && ok) {
             t.w0 = nzmask[(i0 >> 5) * m + j];
             if (i0 + 32 < n) t.w1 = nzmask[((i0 >> 5) + 1) * m + j];
         }
-#endif
     };
 
     TileIn cur;
@@ -237,11 +235,7 @@ __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p
 #pragma unroll
                         for (int rt = 0; rt < 4; ++rt) {
                             const double a = Us[(rt * 16 + lr) * us + 4 * (ks0 + u) + g];
-#ifdef ORIANA_ABL_NOMFMA
-                            acc[rt][0] += a * cur.bq[u];
-#else
                             acc[rt] = mfma_f64(a, cur.bq[u], acc[rt]);
-#endif
                         }
                     }
                 }
@@ -290,19 +284,11 @@ __global__ __launch_bounds__(256, 3) void k_dropout_fused(double *__restrict__ p
                         const int64_t i = i0 + rt * 16 + g + 4 * r;
                         asm volatile("" : "+v"(off));
                         if (i < n) {
-#ifdef ORIANA_ABL_NOSIG
-                            double p = lg - acc[rt][r];
-#else
                             double p = sigmoid_f64(lg - acc[rt][r]);
-#endif
                             if (pi <= 0.0) p = 1e-10;
                             if (pi >= 1.0) p = 1.0 - 1e-10;
                             if ((w >> bit) & 1u) p = 1.0 - 1e-10;
-#ifdef ORIANA_ABL_NOSTORE
-                            if (p == 12345.678) {
-#else
                             {
-#endif
                                 if (p_d) p_d[off] = p;
                                 if (D_hat) D_hat[off] = (float)p;
                             }

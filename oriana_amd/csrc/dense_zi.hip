@@ -89,12 +89,6 @@ __global__ __launch_bounds__(512) void k_zi_images(u4v *__restrict__ img, const 
 // entry l = (X[32 ct + l % 32, 32 gt + 8 (v / 4) + 4 (l / 32) + v % 4] != 0) -- the 16 values lane l of the wave holds, in
 // register order.  One 2-byte LDS read per lane and tile, then v_bfe_i32 (flag -> 0 / ~0) + v_bfi_b32 (select 1.0f) per value:
 // round 3 read the mask words of oriana_nzmask_f32 (bit = cell) and spent and + compare + select per value on the lane's bit.
-#ifndef ORIANA_ZI_TILEMAJOR
-#define ORIANA_ZI_TILEMAJOR 0
-#endif
-#ifndef ORIANA_ZI_MASK_SMEM
-#define ORIANA_ZI_MASK_SMEM 0          // 1 (experiment): the same 128 bytes as 16 pair-ordered 64-bit lane masks, scalar loads
-#endif
 template <int KC, int TAIL>
 __device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const uint32_t *__restrict__ nztiles,
                                             const float *__restrict__ lgit, int64_t mpad, u4v *dst, int gt, int64_t ct_blk0,
@@ -153,11 +147,6 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     const int64_t ct = ct_blk0 + w;                                        // this wave's cell tile
     const int64_t i = ct * 32 + c;
     const int64_t nmrows = (n + 31) / 32;
-#if ORIANA_ZI_MASK_SMEM
-    // (experiment) the wave's 16 lane masks of a tile by SCALAR loads: {word of gene 8 q + e, word of gene 8 q + 4 + e} IS the
-    // lane mask of value 4 q + e -- one v_cndmask per value, but the loads share the LDS counter
-    const uint64_t *mzrow = reinterpret_cast<const uint64_t *>(nztiles) + ct * (int64_t)ngt * 16;
-#endif
     const int gt0 = blockIdx.y * gt_per_split;
     const int gt1 = (gt0 + gt_per_split < ngt) ? gt0 + gt_per_split : ngt;
     if (gt0 >= gt1) return;
@@ -206,15 +195,9 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     // resource's size and the hardware drops the store -- no predicate, no branch; a piece beyond the last gene gets an
     // offset that is out of range.  (num_records <= 32 m floats: 32-bit for any m below 3e7)
     const int64_t rows_here = (n - ct * 32 < 0) ? 0 : (n - ct * 32 > 32 ? 32 : n - ct * 32);
-#if ORIANA_ZI_TILEMAJOR        // (timing experiment: D_hat as [cell tile][gene tile][32 x 32]; every store 1 KB contiguous)
-    __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(D_hat + (rows_here > 0 ? ct * (int64_t)ngt * 1024 : 0), 0,
-                                                                     (int)(rows_here > 0 ? (int64_t)ngt * 4096 : 0), 0x00020000);
-    const uint32_t dvoff = (uint32_t)lane * 16u;
-#else
     __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(D_hat + (rows_here > 0 ? ct * 32 * m : 0), 0,
                                                                      (int)(rows_here * m * 4), 0x00020000);
     const uint32_t dvoff = ((uint32_t)rr * (uint32_t)m + (uint32_t)gq) * 4u;
-#endif
     const int rleft = (int)rows_here - rr;                                 // row rr + 8 q of the read-back is a cell iff 8 q < rleft
 
     auto phase_D = [&](const u4v *im) -> f16v {
@@ -252,11 +235,6 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
 
     zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img, gt0, ct_blk0, ngt, m, w, lane);
     zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + C::PV, (gt0 + 1 < gt1) ? gt0 + 1 : gt0, ct_blk0, ngt, m, w, lane);
-#if ORIANA_ZI_MASK_SMEM
-    uint64_t mk[16];                     // the lane masks of tile gt (loaded one tile ahead, right before the tile barrier)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mk[e] = mzrow[(int64_t)gt0 * 16 + e];
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f16v dn = phase_D(img);              // Lambda^T of tile gt0
@@ -291,9 +269,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
         const f4v *tails = reinterpret_cast<const f4v *>(im0 + C::P1 + C::P2);
         f4v t2 = {0.f, 0.f, 0.f, 0.f};
         f4v lg4 = {0.f, 0.f, 0.f, 0.f}, fl4 = {0.f, 0.f, 0.f, 0.f};
-#if !ORIANA_ZI_MASK_SMEM
         const int nzw = (int)reinterpret_cast<const uint16_t *>(im0 + MP)[w * 64 + lane];      // this lane's 16 non-zero flags
-#endif
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             if (u < KC * 6) {
@@ -330,9 +306,6 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                     float p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(l0[v], 1.4426950408889634f, lgs)));
                     // pi_d <= 0: lgs = +inf -> exp2 = inf -> p = +0, and the gene's floor is 1e-10; every other gene: + 0 (zigap.py:133)
                     p += fl4[v & 3];
-#if ORIANA_ZI_MASK_SMEM
-                    p = __builtin_amdgcn_inverse_ballot_w64(mk[v]) ? 1.0f : p;   // X != 0: f32(1 - 1e-10) == 1      zigap.py:135
-#else
                     {
                         // X != 0: f32(1 - 1e-10) == 1 (zigap.py:135).  (inline assembly: the compiler turns the same two
                         // operations written in C into shift + compare + select + and + or)
@@ -340,7 +313,6 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(nzw), "n"(v));            // flag v -> 0 or ~0
                         asm("v_bfi_b32 %0, %1, 1.0, %2" : "=v"(p) : "v"(sel), "v"(p));            // (sel & 1.0f) | (~sel & p)
                     }
-#endif
                     l0[v] = p;
                     if ((v & 3) == 3)
                         *reinterpret_cast<__attribute__((address_space(3))) f4v *>(Tw0 ^ (uint32_t)(q << 5)) =
@@ -357,12 +329,8 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                     const uint32_t vo = (j0 + gq < m) ? dvoff : 0x80000000u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-#if ORIANA_ZI_TILEMAJOR
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, tq[q]), drsrc, vo, (int)(gt * 4096 + q * 1024), 0);
-#else
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, tq[q]), drsrc, vo,
                                                                (int)((j0 + (int64_t)8 * q * m) * 4), 0);
-#endif
                     // sum_i p_d of the wave's 32 cells: lanes with the same lane % 8 hold the same four genes
                     // (padding cells -- only the matrix's last cell tile has any -- enter with weight 0)
                     f4v cs4 = tq[0] * (0 < rleft ? 1.f : 0.f);
@@ -430,13 +398,6 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#if ORIANA_ZI_MASK_SMEM
-        {
-            const uint64_t *mz = mzrow + (int64_t)((gt + 1 < gt1) ? gt + 1 : gt) * 16;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mk[e] = mz[e];
-        }
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -683,11 +644,6 @@ __global__ void k_nzmask_tiles(uint32_t *__restrict__ out, const uint32_t *__res
     const int gt = (int)(tile - ct * ngt);
     uint32_t o = 0u;
     if (ct < nct) {
-#if ORIANA_ZI_MASK_SMEM
-        const int pr = d >> 1, hh = d & 1, q = pr >> 2, e = pr & 3;        // entry 4 q + e = {gene 8 q + e, gene 8 q + 4 + e}
-        const int64_t j = (int64_t)gt * 32 + 8 * q + 4 * hh + e;
-        o = (j < m) ? nzmask[ct * m + j] : 0u;
-#else
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                             // dword d = lanes 2 d, 2 d + 1
             const int l = 2 * d + half, c = l & 31, h = l >> 5;
@@ -698,7 +654,6 @@ __global__ void k_nzmask_tiles(uint32_t *__restrict__ out, const uint32_t *__res
             }
             o |= f << (16 * half);
         }
-#endif
     }
     out[t] = o;
 }

@@ -640,6 +640,52 @@ extern "C" int oriana_col_pass(const oriana_counts *cm, const float *s_cs, const
     return 0;
 }
 
+// [r6] ANALYSIS entry (tools/parity_report.py): the column pass with float64 accumulators in a fixed
+// order -- one thread per gene and group of 8 factors walks the gene's slots through every row block -- and ONE rounding to
+// float32 at the end: C += f32(sum_i s_ij G_i).  What a compensated (Kahan / two-float) accumulation of the float32 kernels
+// could reach at most; no kernel of a sweep calls it.
+__global__ __launch_bounds__(256) void k_col_pass_f64acc(oriana_counts cm, const float *__restrict__ s_cs,
+                                                         const float *__restrict__ Gm, float *__restrict__ C, int K, int Kp) {
+    const int c = threadIdx.x, sl = c >> 4;
+    const int64_t cb = blockIdx.x, col = cb * TILE + c;
+    const int k0 = blockIdx.y * 8;
+    if (col >= cm.m) return;
+    double acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    for (int64_t rb = 0; rb < cm.nrb; ++rb) {
+        const int64_t t = rb * cm.ncb + cb;
+        const uint32_t s0 = cm.cslice[t * 17 + sl], s1 = cm.cslice[t * 17 + sl + 1];
+        const int ni = (int)((s1 - s0) >> 6);
+        const int64_t base = cm.coff[t] + s0 + (c & 15) * 4;
+        for (int it = 0; it < ni; ++it)
+            for (int r = 0; r < 4; ++r) {
+                const float sv = s_cs[base + (int64_t)it * 64 + r];
+                if (sv == 0.f) continue;
+                const int64_t row = rb * TILE + cm.ridx[base + (int64_t)it * 64 + r];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + e < K) acc[e] += (double)sv * (double)Gm[row * Kp + k0 + e];
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (k0 + e < K) C[col * Kp + k0 + e] += (float)acc[e];
+}
+
+extern "C" int oriana_col_pass_f64acc(const oriana_counts *cm, const float *s_cs, const float *Gm, float *C, int64_t K,
+                                      void *stream) {
+    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
+    const int64_t Kp = oriana_kpad(K);
+    if (Kp == 0) return ORIANA_EKRANGE;
+    if (cm->n == 0 || cm->m == 0) return 0;
+    if (!Gm || !C || !s_cs) return ORIANA_EINVAL;
+    hipLaunchKernelGGL(k_col_pass_f64acc, dim3((unsigned)cm->ncb, (unsigned)((K + 7) / 8)), dim3(256), 0, (hipStream_t)stream, *cm,
+                       s_cs, Gm, C, (int)K, (int)Kp);
+    ORIANA_LAUNCH_CHECK();
+    return 0;
+}
+
 // two images, one column tile per work item (work list of width 1)
 template <int G, int T4, int TAIL>
 static int launch_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,

@@ -318,6 +318,11 @@ struct oriana_resident {
     int32_t *dn_flag = nullptr;
     // the ZI / sparse nests (allocated on first use)
     float *w_nz = nullptr, *sw_cs = nullptr, *s_rs = nullptr, *F2 = nullptr, *G2 = nullptr, *C2 = nullptr, *dq = nullptr;
+    float *GQ = nullptr;
+    // [r6] work list of the dual column pass (one column tile per item) and the caller's declaration about D_hat
+    int32_t *col_work1 = nullptr;
+    int64_t n_col_work1 = 0;
+    int unit_dropout = 0;
 };
 
 namespace {
@@ -509,6 +514,16 @@ int resident_build(oriana_resident *h, ChunkSource &src, double dense_density, h
             RES_TRY(dev_alloc(h, &h->col_work, (size_t)std::max<int64_t>(h->n_col_work * 3, 1), false, s));
             ORIANA_HIP_CHECK(hipMemcpyAsync(h->col_work, items.data(), sizeof(int32_t) * h->n_col_work * 3, hipMemcpyHostToDevice, s));
             ORIANA_HIP_CHECK(hipStreamSynchronize(s));
+            // the dual column pass of the sparse nests (two factor images per tile: one column tile per item)
+            if (width == 1) { h->col_work1 = h->col_work; h->n_col_work1 = h->n_col_work; }
+            else {
+                const int64_t cap1 = oriana_plan_col_work_capacity(h->nrb, h->ncb, 1);
+                std::vector<int32_t> items1((size_t)cap1 * 3);
+                RES_TRY(oriana_plan_col_work(longest.data(), h->nrb, h->ncb, 1, h->cus, 0, 1, 0, items1.data(), cap1, &h->n_col_work1));
+                RES_TRY(dev_alloc(h, &h->col_work1, (size_t)std::max<int64_t>(h->n_col_work1 * 3, 1), false, s));
+                ORIANA_HIP_CHECK(hipMemcpyAsync(h->col_work1, items1.data(), sizeof(int32_t) * h->n_col_work1 * 3, hipMemcpyHostToDevice, s));
+                ORIANA_HIP_CHECK(hipStreamSynchronize(s));
+            }
         }
     }
     h->nslab = h->split.parts;
@@ -561,6 +576,8 @@ extern "C" int oriana_counts_create_dense_f32(oriana_resident **out, const float
 extern "C" int oriana_counts_create_csr(oriana_resident **out, const int64_t *indptr, const int32_t *indices, const float *data,
                                         int64_t n, int64_t m, int64_t K, double dense_density, void *stream) {
     if (!indptr || (n > 0 && indptr[n] > indptr[0] && (!indices || !data))) return ORIANA_EINVAL;
+    for (int64_t r = 0; r < n; ++r)
+        if (indptr[r + 1] < indptr[r]) return ORIANA_EINVAL;          // (a non-monotone indptr would send the scatter kernel out of bounds)
     for (int64_t e = indptr[0]; n > 0 && e < indptr[n]; ++e)
         if (indices[e] < 0 || indices[e] >= m) return ORIANA_EINVAL;
     ChunkSource src;
@@ -628,26 +645,138 @@ extern "C" int oriana_zq_gap_resident(oriana_resident *h, float *Z_i, float *Z_j
     return oriana_finalize(Z_j, h->FV, h->C, nullptr, h->col_perm, m, K, 1, stream);
 }
 
-// The ZI / sparse nests on a resident SLICED layout (a hybrid handle serves the pCMF nest only): the kernel sequence of the
-// stateless entries (stateless.hip: zq_dense) without the packing; D_hat is gathered at the stored entries on every call.
+// [r6] The ZI / sparse nests WITHOUT per-entry weights -- D_hat == 1 at every stored entry, which is what every D_hat the
+// reference's own models hand to these nests looks like (zigap.py:135 sets p_d = 1 - 1e-10 at the non-zero counts, bernoulli.py:45
+// casts it to float32 = 1) and what the caller declares with oriana_counts_declare_unit_dropout -- as engine.zq runs them for the
+// model classes: sliced or hybrid layout; Kp <= 64: the sparse nests' S_hat-weighted row sums out of the fused two-image row
+// pass and both per-gene sums out of one dual column pass; above: den-only row pass + second row product + two column passes.
+// D_hat itself is read for the D_hat[i, k] weights of zigap.py:94 only (dq).  Zlog may be NULL (the reference's caller never
+// reads its third output, zigap.py:105-112): the log sums are then skipped.
+static int zq_unit_resident(oriana_resident *h, float *Zi, float *Zj, float *Zlog, const float *log_U_hat, const float *log_V_hat,
+                            const float *S_tilde, const float *S_hat, const float *D_hat, int quirk, void *stream) {
+    const int64_t n = h->n, m = h->m, K = h->K, Kp = h->Kp, gd = h->gd;
+    hipStream_t s = (hipStream_t)stream;
+    const bool sparse = S_hat != nullptr, have_sliced = h->ms > 0 || gd == 0;
+    const size_t rs1 = (size_t)std::max<int64_t>(h->rslots, 1);
+    // (every buffer of a group is tested on its own: a failed allocation must not leave a later call with a NULL sibling)
+    if (sparse && !h->F2) RES_TRY(dev_alloc(h, &h->F2, (size_t)(m * Kp), true, s));
+    if (Zlog && !h->G2) RES_TRY(dev_alloc(h, &h->G2, (size_t)(n * Kp), true, s));
+    if (Zlog && !h->C2) RES_TRY(dev_alloc(h, &h->C2, (size_t)(m * Kp), true, s));
+    if (quirk && !h->dq) RES_TRY(dev_alloc(h, &h->dq, (size_t)(n * K), true, s));
+    if (quirk && !h->GQ) RES_TRY(dev_alloc(h, &h->GQ, (size_t)(n * Kp), true, s));
+    const float *den_min = reinterpret_cast<const float *>(reinterpret_cast<const char *>(h->prep) + oriana_prep_den_threshold_offset());
+    const int64_t r_rows = n + (h->nslab - 1) * (n - (int64_t)h->split.nfull * TILE);
+    oriana_clear_list cl;
+    memset(&cl, 0, sizeof(cl));
+    int e = 0;
+    cl.ptr[e] = Zi; cl.bytes[e++] = (int64_t)sizeof(float) * n * K;
+    cl.ptr[e] = Zj; cl.bytes[e++] = (int64_t)sizeof(float) * m * K;
+    cl.ptr[e] = h->C; cl.bytes[e++] = (int64_t)sizeof(float) * m * Kp;
+    cl.ptr[e] = h->tile_flag; cl.bytes[e++] = (int64_t)sizeof(int32_t) * std::max<int64_t>(h->nt, 1);
+    if (Zlog) { cl.ptr[e] = Zlog; cl.bytes[e++] = (int64_t)sizeof(float) * m * K; cl.ptr[e] = h->C2; cl.bytes[e++] = (int64_t)sizeof(float) * m * Kp; }
+    if (!have_sliced) { cl.ptr[e] = h->R; cl.bytes[e++] = (int64_t)sizeof(float) * r_rows * Kp; }
+    RES_TRY(oriana_factor_prep_pair_clear(h->FU, h->FV, log_U_hat, log_V_hat, S_tilde, nullptr, h->col_perm, n, m, K, h->prep, &cl, stream));
+    float *dq = nullptr;
+    if (quirk) { dq = h->dq; RES_TRY(oriana_take_cols_f32(dq, D_hat, n, m, K, stream)); }
+    if (sparse) RES_TRY(oriana_scale_factor(h->F2, h->FV, S_hat, h->col_perm, m, K, 0, stream));
+    const int64_t goff = gd * Kp;
+    const int variant = (sparse ? 1 : 0) | (dq ? 4 : 0);
+    int64_t nslab = 1;
+    if (have_sliced) {
+        bool fused = false;
+        if (sparse) {
+            const int rc = oriana_row_pass_general(&h->cm, h->FU, h->FV + goff, h->F2 + goff, nullptr, h->R, h->s_cs, nullptr, nullptr,
+                                                   h->tile_flag, K, &h->split, den_min, stream);
+            if (rc != 0 && rc != ORIANA_EKRANGE) return rc;
+            fused = rc == 0;
+        }
+        float *s_rs = nullptr;
+        if (!fused) {
+            if (sparse) { if (!h->s_rs) RES_TRY(dev_alloc(h, &h->s_rs, rs1, true, s)); s_rs = h->s_rs; }
+            RES_TRY(oriana_row_pass_general(&h->cm, h->FU, h->FV + goff, nullptr, nullptr, h->R, h->s_cs, nullptr, s_rs, h->tile_flag, K,
+                                            &h->split, den_min, stream));
+        }
+        if (fused || !sparse) nslab = h->nslab;              // (the second row product of the unfused sparse form writes one slab)
+        RES_TRY(oriana_fixup(&h->cm, h->tile_flag, h->s_cs, nullptr, s_rs, log_U_hat, log_V_hat, S_tilde, S_hat, nullptr, dq, Zi, Zj, Zlog, K,
+                             variant, stream));
+        if (sparse && !fused) RES_TRY(oriana_row_spmm(&h->cm, s_rs, nullptr, h->F2 + goff, h->R, K, stream));
+    }
+    if (gd > 0) {
+        RES_TRY(oriana_dense_images2(h->dn_imgV, h->FV, sparse ? h->F2 : nullptr, gd, K, 0, stream));
+        int64_t tail_nfull = 0, tail_parts = 1;
+        if (h->split.nfull > 0 && 1 < h->split.parts && h->split.parts == nslab && h->dn_gene_splits == 1 && h->split.parts <= gd / 32) {
+            tail_nfull = h->split.nfull; tail_parts = h->split.parts;
+        }
+        RES_TRY(oriana_dense_row_pass_tail(&h->dn, h->FU, h->dn_imgV, h->R, h->dn_S, h->dn_flag, K, h->dn_gene_splits, tail_nfull, tail_parts,
+                                           den_min, stream));
+        RES_TRY(oriana_dense_fixup_variant(&h->dn, h->dn_flag, h->dn_S, log_U_hat, log_V_hat, nullptr, h->col_perm, Zi, Zj, Zlog, dq, S_tilde,
+                                           S_hat, K, 0, stream));
+    }
+    RES_TRY(oriana_finalize_slabs_from(Zi, h->FU, h->R, nslab, (int64_t)h->split.nfull * TILE, nullptr, n, K, stream));
+    double *center = reinterpret_cast<double *>(reinterpret_cast<char *>(h->prep) + oriana_prep_center_offset());
+    if (Zlog) {
+        RES_TRY(oriana_log_center(center, h->FU, log_U_hat, Zi, nullptr, n, K, stream));
+        RES_TRY(oriana_scale_factor_centered(h->G2, h->FU, log_U_hat, center, nullptr, n, K, stream));
+    }
+    // ---- per-gene sums
+    auto dense_cols = [&](const float *G, float *Cm) -> int {
+        RES_TRY(oriana_dense_images(h->dn_imgU, G, n, K, 1, stream));
+        return oriana_dense_col_pass(&h->dn, h->dn_imgU, h->dn_S, Cm, K, h->dn_cell_splits, stream);
+    };
+    auto dual = [&](bool *done) -> int {          // C += s FU and C2 += s G2 from one walk over the stream, where two images fit
+        *done = false;
+        if (!h->col_work1) return 0;
+        const int rc = oriana_col_pass_dual(&h->cm, h->s_cs, h->FU, h->G2, h->C + goff, h->C2 + goff, K, h->col_work1, h->n_col_work1, stream);
+        if (rc != 0 && rc != ORIANA_EKRANGE) return rc;
+        *done = rc == 0;
+        return 0;
+    };
+    const float *G = h->FU;
+    if (dq) { RES_TRY(oriana_scale_factor(h->GQ, h->FU, dq, nullptr, n, K, 0, stream)); G = h->GQ; }
+    bool dual_done = false;
+    if (Zlog && !dq && have_sliced) RES_TRY(dual(&dual_done));
+    if (!dual_done && have_sliced) RES_TRY(oriana_col_pass(&h->cm, h->s_cs, G, h->C + goff, K, h->col_work, h->n_col_work, stream));
+    if (gd > 0) RES_TRY(dense_cols(G, h->C));
+    RES_TRY(oriana_finalize(Zj, h->FV, h->C, nullptr, h->col_perm, m, K, 1, stream));
+    if (Zlog) {
+        if (dq) {                                 // the log sums use the plain column sums (zigap.py:95), Z_j the D_hat[i, k]-weighted ones
+            ORIANA_HIP_CHECK(hipMemsetAsync(h->C, 0, sizeof(float) * m * Kp, s));
+            if (have_sliced) {
+                RES_TRY(dual(&dual_done));
+                if (!dual_done) RES_TRY(oriana_col_pass(&h->cm, h->s_cs, h->FU, h->C + goff, K, h->col_work, h->n_col_work, stream));
+            }
+            if (gd > 0) RES_TRY(dense_cols(h->FU, h->C));
+        }
+        if (!dual_done && have_sliced) RES_TRY(oriana_col_pass(&h->cm, h->s_cs, h->G2, h->C2 + goff, K, h->col_work, h->n_col_work, stream));
+        if (gd > 0) RES_TRY(dense_cols(h->G2, h->C2));
+        RES_TRY(oriana_finalize_zlog(Zlog, h->FV, h->C2, h->C, log_V_hat, center, h->col_perm, m, K, stream));
+    }
+    return 0;
+}
+
+// The ZI / sparse nests with a GENERAL D_hat (any weight at the stored entries) on a resident SLICED layout: the kernel sequence
+// of the stateless entries (stateless.hip: zq_dense) without the packing; D_hat is gathered at the stored entries on every call.
+// The dense-gene kernels of a hybrid layout carry no per-entry weights: a hybrid handle serves these nests under the unit
+// declaration (above) only.
 static int zq_variant_resident(oriana_resident *h, float *Zi, float *Zj, float *Zlog, const float *log_U_hat, const float *log_V_hat,
                                const float *S_tilde, const float *S_hat, const float *D_hat, int quirk, void *stream) {
     if (!h || !Zi || !Zj || !log_U_hat || !log_V_hat) return ORIANA_EINVAL;
-    if (h->gd > 0) return ORIANA_EINVAL;
     if ((S_tilde == nullptr) != (S_hat == nullptr)) return ORIANA_EINVAL;
     const int64_t n = h->n, m = h->m, K = h->K, Kp = h->Kp;
     if (quirk && (!D_hat || K > m)) return ORIANA_EQUIRK;
+    if (!D_hat || h->unit_dropout)
+        return zq_unit_resident(h, Zi, Zj, Zlog, log_U_hat, log_V_hat, S_tilde, S_hat, D_hat, quirk, stream);
+    if (h->gd > 0) return ORIANA_EUNIT;
     hipStream_t s = (hipStream_t)stream;
     const bool sparse = S_hat != nullptr, weighted = D_hat != nullptr;
     const size_t rs1 = (size_t)std::max<int64_t>(h->rslots, 1), cs1 = (size_t)std::max<int64_t>(h->cslots, 1);
-    if (weighted && !h->w_nz) { RES_TRY(dev_alloc(h, &h->w_nz, rs1, true, s)); RES_TRY(dev_alloc(h, &h->sw_cs, cs1, true, s)); }
+    if (weighted && !h->w_nz) RES_TRY(dev_alloc(h, &h->w_nz, rs1, true, s));
+    if (weighted && !h->sw_cs) RES_TRY(dev_alloc(h, &h->sw_cs, cs1, true, s));
     if (sparse && !h->s_rs) RES_TRY(dev_alloc(h, &h->s_rs, rs1, true, s));
-    if ((sparse || Zlog || quirk) && !h->F2) {
-        RES_TRY(dev_alloc(h, &h->F2, (size_t)(m * Kp), true, s));
-        RES_TRY(dev_alloc(h, &h->G2, (size_t)(n * Kp), true, s));
-        RES_TRY(dev_alloc(h, &h->C2, (size_t)(m * Kp), true, s));
-        RES_TRY(dev_alloc(h, &h->dq, (size_t)(n * K), true, s));
-    }
+    if (sparse && !h->F2) RES_TRY(dev_alloc(h, &h->F2, (size_t)(m * Kp), true, s));
+    if ((Zlog || quirk) && !h->G2) RES_TRY(dev_alloc(h, &h->G2, (size_t)(n * Kp), true, s));
+    if (Zlog && !h->C2) RES_TRY(dev_alloc(h, &h->C2, (size_t)(m * Kp), true, s));
+    if (quirk && !h->dq) RES_TRY(dev_alloc(h, &h->dq, (size_t)(n * K), true, s));
     const float *den_min = reinterpret_cast<const float *>(reinterpret_cast<const char *>(h->prep) + oriana_prep_den_threshold_offset());
     oriana_clear_list cl;
     memset(&cl, 0, sizeof(cl));
@@ -697,10 +826,16 @@ static int zq_variant_resident(oriana_resident *h, float *Zi, float *Zj, float *
     return 0;
 }
 
+extern "C" int oriana_counts_declare_unit_dropout(oriana_resident *h, int on) {
+    if (!h) return ORIANA_EINVAL;
+    h->unit_dropout = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int oriana_zq_zigap_resident(oriana_resident *h, float *DZ_hat_i, float *DZ_hat_j, float *DZ_exp_logsum_hat,
                                         const float *log_U_hat, const float *log_V_hat, const float *D_hat, int reference_quirks,
                                         void *stream) {
-    if (!D_hat || !DZ_exp_logsum_hat) return ORIANA_EINVAL;
+    if (!D_hat) return ORIANA_EINVAL;
     return zq_variant_resident(h, DZ_hat_i, DZ_hat_j, DZ_exp_logsum_hat, log_U_hat, log_V_hat, nullptr, nullptr, D_hat,
                                reference_quirks ? 1 : 0, stream);
 }

@@ -713,11 +713,17 @@ def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None, clear=None):
          ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), stream_ptr())
 
 
+_COL_F64 = os.environ.get('ORIANA_COL_F64') == '1'     # analysis runs (tools/parity_report.py): float64 accumulators, one rounding
+
+
 def col_pass(ct, s_cs, G, C, K, C_ptr=None):
     """C += s G over the sliced layout.  `C_ptr`: device address of the first gene row of the sliced layout inside C
     (hybrid layouts: gd rows in)."""
     w = ct.col_work_for(K)
     Cp = ptr(C) if C_ptr is None else C_ptr
+    if _COL_F64:
+        call('oriana_col_pass_f64acc', ct.sparse_struct, ptr(s_cs), ptr(G), Cp, K, stream_ptr())
+        return
     if DETERMINISTIC and w is not None:
         nbytes = int(_lib.load().oriana_col_pass_det_scratch_bytes(int(K), int(w.shape[0])))
         key = (ct.device, nbytes)
@@ -734,7 +740,7 @@ def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K, goff=0):
     """C1 += s G1 and C2 += s G2 from one walk over the column-side stream (oriana_col_pass_dual).  Returns False when
     the two factor images do not fit in LDS (or in the deterministic debug mode): the caller runs two column passes.
     `goff`: byte offset of the sliced part's first gene row inside C1 / C2 (hybrid layouts)."""
-    if DETERMINISTIC or not _FUSE_SPARSE_COLS:
+    if DETERMINISTIC or not _FUSE_SPARSE_COLS or _COL_F64:
         return False
     w = ct.col_work_width(1)
     if w is None:

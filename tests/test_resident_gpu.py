@@ -120,8 +120,69 @@ def test_resident_from_csr_equals_dense(lib):
     assert err_colrel(outs[1][1], outs[0][1]) < 1e-6 and err_colrel(outs[1][2], outs[0][2]) < 1e-6
 
 
+@pytest.mark.parametrize('dd', [0.0, 0.2], ids=['sliced', 'hybrid'])
+@pytest.mark.parametrize('K', [20, 50, 64, 100])
+def test_twins_resident_match_oracle(lib, K, dd):
+    """[r6] zigap.py:79-95 (both index conventions of :94; with and without its third output), sparse_gap.py:81-97,
+    sparse_zigap.py:100-116 under oriana_counts_declare_unit_dropout -- D_hat == 1 at the non-zero counts, as every D_hat of the
+    reference's own models is -- on a sliced and on a HYBRID handle, through the kernels the model classes use (K = 20: four
+    lanes per row; 50, 64: the two-lane k64 kernels, fused two-image row pass + dual column pass for the sparse nests; 100:
+    k100 + the four-kernel sparse form), against the C oracle with the same D_hat; a dead gene; repeated calls on one handle."""
+    from oracle import cavi_oracle as co
+    from oriana_amd._lib import ptr, stream_ptr
+    n, m = 900, 420
+    rng, X, lu, lv = _data(200 + K, n, m, K, z=0.3)
+    D = rng.random((n, m)).astype(np.float32)
+    D[X != 0] = 1.0                                                        # zigap.py:135 + bernoulli.py:45
+    St = (rng.random((m, K)) < 0.7).astype(np.float32)
+    dead = int(np.argsort((X != 0).sum(0))[m // 2])
+    St[dead] = 0.0                                                         # a gene with no active factor (sliced part)
+    St[int(np.argmax((X != 0).sum(0)))] = 0.0                              # ... and the densest gene (dense block of the hybrid handle)
+    Sh = rng.random((m, K)).astype(np.float32)
+    h = _create(lib, X, K, dd)
+    assert (_info(lib, h)[5] > 0) == (dd > 0)
+    assert lib.oriana_counts_declare_unit_dropout(h, 1) == 0
+    d = lambda a: torch.from_numpy(a).cuda()
+    lud, lvd, Dd, Std, Shd = d(lu), d(lv), d(D), d(St), d(Sh)
+    Zi, Zj, Zl = torch.empty(n, K, device='cuda'), torch.empty(m, K, device='cuda'), torch.empty(m, K, device='cuda')
+    rZi, rZj, rZl = np.empty((n, K), np.float32), np.empty((m, K), np.float32), np.empty((m, K), np.float32)
+    st = stream_ptr()
+    for quirk in (1, 0):
+        co.zq_zigap(rZi, rZj, rZl, lu, lv, D, X, quirk=bool(quirk))
+        for with_log in (True, False):
+            Zl.fill_(7.0)
+            assert lib.oriana_zq_zigap_resident(h, ptr(Zi), ptr(Zj), ptr(Zl) if with_log else None, ptr(lud), ptr(lvd), ptr(Dd), quirk, st) == 0
+            torch.cuda.synchronize()
+            assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5 and err_colrel(Zj.cpu().numpy(), rZj) < 1e-5, (quirk, with_log)
+            if with_log:
+                assert err_colrel(Zl.cpu().numpy(), rZl) < 2e-5, quirk
+            else:
+                assert bool((Zl == 7.0).all())                            # NULL: the log sums are skipped, nothing written
+    for rep in range(2):                                                   # (twice: the handle's scratch of the first call is reused)
+        assert lib.oriana_zq_sparse_gap_resident(h, ptr(Zi), ptr(Zj), ptr(Zl), ptr(lud), ptr(lvd), ptr(Std), ptr(Shd), st) == 0
+        torch.cuda.synchronize()
+        co.zq_sparse_gap(rZi, rZj, rZl, lu, lv, St, Sh, X)
+        assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5 and err_colrel(Zj.cpu().numpy(), rZj) < 1e-5
+        assert err_colrel(Zl.cpu().numpy(), rZl) < 2e-5 and not Zj[dead].any()
+    assert lib.oriana_zq_sparse_zigap_resident(h, ptr(Zi), ptr(Zj), ptr(Zl), ptr(lud), ptr(lvd), ptr(Std), ptr(Shd), ptr(Dd), st) == 0
+    torch.cuda.synchronize()
+    co.zq_sparse_zigap(rZi, rZj, rZl, lu, lv, St, Sh, D, X)
+    assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5 and err_colrel(Zj.cpu().numpy(), rZj) < 1e-5
+    assert err_colrel(Zl.cpu().numpy(), rZl) < 2e-5
+    # the pCMF nest still runs on the same handle afterwards
+    assert lib.oriana_zq_gap_resident(h, ptr(Zi), ptr(Zj), ptr(lud), ptr(lvd), st) == 0
+    torch.cuda.synchronize()
+    co.zq_gap(rZi, rZj, lu, lv, X)
+    assert err_colrel(Zi.cpu().numpy(), rZi) < 1e-5 and err_colrel(Zj.cpu().numpy(), rZj) < 1e-5
+    # without the declaration: a general D_hat on the sliced handle (below), ORIANA_EUNIT on the hybrid one
+    assert lib.oriana_counts_declare_unit_dropout(h, 0) == 0
+    rc = lib.oriana_zq_zigap_resident(h, ptr(Zi), ptr(Zj), ptr(Zl), ptr(lud), ptr(lvd), ptr(Dd), 1, st)
+    assert rc == (-4 if dd > 0 else 0)
+    lib.oriana_counts_destroy(h)
+
+
 @pytest.mark.parametrize('K', [7, 20, 50, 64, 100])
-def test_twins_resident_match_oracle(lib, K):
+def test_twins_resident_general_weights(lib, K):
     """zigap.py:79-95 (both index conventions of :94), sparse_gap.py:81-97, sparse_zigap.py:100-116 with a general D_hat
     (gathered at the stored entries on every call) and a dead gene."""
     from oracle import cavi_oracle as co
@@ -177,7 +238,7 @@ def test_resident_argument_errors(lib):
     assert not Zi.any() and not Zj.any()
     assert lib.oriana_zq_gap_resident(h, None, ptr(Zj), ptr(l), ptr(l), stream_ptr()) == -1
     assert lib.oriana_counts_destroy(h) == 0 and lib.oriana_counts_destroy(None) == 0
-    # a hybrid handle serves the pCMF nest only
+    # a hybrid handle serves the ZI nests under the unit declaration only (the dense-gene kernels carry no per-entry weights)
     rng = np.random.default_rng(0)
     Xh = (rng.random((300, 64)) < 0.6).astype(np.float32)
     hh = _create(lib, Xh, 20, 0.3)
@@ -185,7 +246,11 @@ def test_resident_argument_errors(lib):
     Zl = torch.empty(64, 20, device='cuda')
     D = torch.ones(300, 64, device='cuda')
     Zi2, Zj2, l1, l2 = torch.empty(300, 20, device='cuda'), torch.empty(64, 20, device='cuda'), torch.zeros(300, 20, device='cuda'), torch.zeros(64, 20, device='cuda')
-    assert lib.oriana_zq_zigap_resident(hh, ptr(Zi2), ptr(Zj2), ptr(Zl), ptr(l1), ptr(l2), ptr(D), 0, stream_ptr()) == -1
+    assert lib.oriana_zq_zigap_resident(hh, ptr(Zi2), ptr(Zj2), ptr(Zl), ptr(l1), ptr(l2), ptr(D), 0, stream_ptr()) == -4
+    assert lib.oriana_counts_declare_unit_dropout(hh, 1) == 0 and lib.oriana_counts_declare_unit_dropout(None, 1) == -1
+    assert lib.oriana_zq_zigap_resident(hh, ptr(Zi2), ptr(Zj2), ptr(Zl), ptr(l1), ptr(l2), ptr(D), 0, stream_ptr()) == 0
+    assert lib.oriana_zq_zigap_resident(hh, ptr(Zi2), ptr(Zj2), ptr(Zl), ptr(l1), ptr(l2), None, 0, stream_ptr()) == -1
+    torch.cuda.synchronize()
     lib.oriana_counts_destroy(hh)
 
 
@@ -243,3 +308,6 @@ def test_resident_edge_shapes_and_ineligible_genes(lib):
     bad = indices.copy(); bad[10] = m
     h2 = ctypes.c_void_p(None)
     assert lib.oriana_counts_create_csr(ctypes.addressof(h2), indptr.ctypes.data, bad.ctypes.data, data.ctypes.data, n, m, K, 0.0, stream_ptr()) == -1
+    r = int(np.nonzero(np.diff(indptr)[1:] > 0)[0][0]) + 1                  # a non-monotone indptr: row r "ends before it starts"
+    badp = indptr.copy(); badp[r] = indptr[r + 1] + 1
+    assert lib.oriana_counts_create_csr(ctypes.addressof(h2), badp.ctypes.data, indices.ctypes.data, data.ctypes.data, n, m, K, 0.0, stream_ptr()) == -1

@@ -1,7 +1,9 @@
 # -*- coding: utf-8 -*-
-"""Files the counter passes of tools/evidence_r04_pmc.sh (gpurun_out/r04/r04_<workload>_{sq1,sq2,fetch,write}.json) under
-profiles/: r04_sq_secondary.json (what binds the kernels of configs[2] / configs[4]) and r04_pmc_hbm_<workload>.json (HBM
-traffic per sweep, with the guide's gfx950 correction spelled out per kernel) -- the `roofline.traffic` of those workloads."""
+"""usage: python tools/assemble_profiles_pmc.py <round tag>
+Files the counter passes of `tools/evidence_pmc.sh <round tag>` (gpurun_out/<round>/<round>_<workload>_{sq1,sq2,fetch,write}.json)
+under profiles/: <round>_sq_secondary.json (what binds the kernels of configs[2] / configs[4]), <round>_pmc_hbm_<workload>.json (HBM
+traffic per sweep, with the guide's gfx950 correction spelled out per kernel -- the `roofline.traffic` of those workloads),
+<round>_pmc_hbm_c4_hybrid.json and <round>_sq_pass_c4_hybrid.json for the headline.  Every file records the command that ran."""
 import json
 import os
 import sys
@@ -54,7 +56,7 @@ for w in ('c3_zi', 'c5_sparse'):
         tr[k] = ((2.0 if any(x in k for x in WIDE) else 1.0) * f + wv) * KiB
     tr['total'] = sum(tr.values())
     json.dump({'command': ('rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload %s --steps 3 --warmup 1 --no-cpu '
-                           '(and a second, separate pass with --pmc WRITE_SIZE); tools/evidence_%s_pmc.sh') % (w, RND),
+                           '(and a second, separate pass with --pmc WRITE_SIZE); tools/evidence_pmc.sh %s') % (w, RND),
                'workload': w, 'n_gpus': 1, 'unit': 'KB per launch (one launch of each kernel per sweep), as rocprofv3 reports them',
                'counters': raw,
                'corrections': 'MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read.  Doubled: '
@@ -64,7 +66,7 @@ for w in ('c3_zi', 'c5_sparse'):
                'traffic_bytes_per_pass': tr, 'algorithmic_bytes': ALG[w]}, open(P + '%s_pmc_hbm_%s.json' % (RND, w), 'w'), indent=1)
     print(w, 'traffic per sweep %.1f GB against %.1f GB algorithmic' % (tr['total'] / 1e9, ALG[w] / 1e9), {k[:28]: round(v / 1e9, 2) for k, v in tr.items()})
 if sq_all:
-  json.dump({'command': 'tools/evidence_' + RND + '_pmc.sh: two rocprofv3 --pmc passes per workload (8 SQ counters + GRBM_GUI_ACTIVE; counters only with --kernel-trace) over '
+  json.dump({'command': 'tools/evidence_pmc.sh ' + RND + ': two rocprofv3 --pmc passes per workload (8 SQ counters + GRBM_GUI_ACTIVE; counters only with --kernel-trace) over '
                       'python3 bench.py --workload {c3_zi, c5_sparse} --steps 3 --warmup 1 --no-cpu',
            'unit': 'per launch; wave-cycle shares of SQ_WAVE_CYCLES; busy fractions of the kernel\'s cycles x 1024 SIMDs',
            'derived': sq_all}, open(P + RND + '_sq_secondary.json', 'w'), indent=1)
@@ -72,7 +74,7 @@ for w, der in sq_all.items():
     for k, e in der.items():
         print(w, k[:40], {a: round(b, 3) for a, b in e.items() if 'fraction' in a or 'wave_cycles' in a})
 
-# ---- C4, hybrid layout, final build (tools/evidence_r04_pmc_c4.sh)
+# ---- C4, hybrid layout, final build
 try:
     fe = json.load(open(F + RND + '_c4_fetch.json'))['per_dispatch_mean']
     wr = json.load(open(F + RND + '_c4_write.json'))['per_dispatch_mean']
@@ -94,7 +96,7 @@ if fe is not None:
     tr['total'] = sum(tr.values())
     names = ('k_row_pass', 'k_col_pass', 'k_dn_row', 'k_dn_col', 'k_dn_images<6, 1, true>', 'k_dn_images<6, 1, false>', 'k_fixup', 'k_dn_fixup')
     json.dump({'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu   (and a second, '
-                          'separate pass with --pmc WRITE_SIZE); tools/evidence_' + RND + '_pmc_c4.sh', 'workload': 'c4',
+                          'separate pass with --pmc WRITE_SIZE); tools/evidence_pmc.sh ' + RND, 'workload': 'c4',
                'layout': 'hybrid, threshold 0.2 (4064 dense genes); the row blocks of the last round of both row kernels split into three gene ranges',
                'n_gpus': 1, 'unit': 'KB per launch, averaged over the launches of the run, as rocprofv3 reports them',
                'counters': {k: {'FETCH_SIZE': g(fe, k), 'WRITE_SIZE': g(wr, k)} for k in names},
@@ -118,7 +120,7 @@ if fe is not None:
             e['matrix_pipe_busy_fraction'] = n['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / clk
             e['valu_instructions_per_matrix_instruction'] = n['SQ_INSTS_VALU'] / n['SQ_INSTS_MFMA']
         der[k] = e
-    json.dump({'command': 'tools/evidence_' + RND + '_pmc_c4.sh: two rocprofv3 --pmc passes (8 SQ counters + GRBM_GUI_ACTIVE, counters only with --kernel-trace) over '
+    json.dump({'command': 'tools/evidence_pmc.sh ' + RND + ': two rocprofv3 --pmc passes (8 SQ counters + GRBM_GUI_ACTIVE, counters only with --kernel-trace) over '
                           'python3 bench.py --steps 2 --warmup 1 --no-cpu (c4, hybrid layout, final build)',
                'unit': 'per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles',
                'counters': sq, 'derived': der}, open(P + RND + '_sq_pass_c4_hybrid.json', 'w'), indent=1)

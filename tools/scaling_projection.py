@@ -5,7 +5,9 @@ any round: every figure below the one-GPU rows is a projection, labelled as such
 
     python tools/scaling_projection.py c4.json c4_half.json c4_quarter.json c4_eighth.json [out.json]
 
-Per share: the step time, the kernels of the pass, the fixed part (cell- and gene-side updates, M-step, preparation, launch
+The shares should be measured with ORIANA_BENCH_FORCE_PG=1 (tools/evidence.sh does): the sweep then runs the sharded code path
+over a one-rank nccl group -- packed Z_j order, the extra gene-side finalize, the exchange's synchronisation points -- so that only
+the wire time of the collectives is modelled.  Per share: the step time, the kernels of the pass, the fixed part (cell- and gene-side updates, M-step, preparation, launch
 gaps = step - pass) -- all measured.  The exchange of a sharded sweep: one float64 all-reduce of the
 rate partials (2K doubles, started before the column pass), the float32 all-reduce of the per-gene sums Z_j in two
 segments -- the sliced genes' segment (m - gd rows) travels under the dense gene-side kernel, the dense genes' gd rows
@@ -52,7 +54,12 @@ def main():
         f64_bytes = 8.0 * 2 * K
         exposed = ring_ms(f32_bytes - dense_bytes, N) + ring_ms(dense_bytes, N) + ring_ms(f64_bytes, N) if N > 1 else 0.0
         hidden = ring_ms(dense_bytes, N) if N > 1 else 0.0
-        row = {'gpus': N, 'rows_per_rank': cfg['rows_per_rank'], 'measured_on': '1 GPU (this share alone)',
+        sharded = 'exchange_rehearsal' in d        # ORIANA_BENCH_FORCE_PG=1: the share ran the SHARDED sweep over a one-rank nccl group
+        row = {'gpus': N, 'rows_per_rank': cfg['rows_per_rank'],
+               'measured_on': ('1 GPU, this share alone, through the sharded code path (one-rank nccl group: packed Z_j order, gene-side '
+                               'finalize, every collective issued as a self all-reduce)' if sharded else
+                               '1 GPU (this share alone, unsharded code path: the packed exchange order and its extra gene-side launch '
+                               'are NOT in the step time)'),
                'step_ms': step, 'pass_ms': pass_ms, 'fixed_ms': step - pass_ms, 'kernel_ms': ks,
                'exchange_bytes_f32': f32_bytes, 'exchange_bytes_f32_dense_segment': dense_bytes, 'exchange_bytes_f64': f64_bytes,
                'exchange_ms_exposed_model': exposed, 'exchange_ms_hidden_model': hidden,

@@ -62,6 +62,75 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// [r6] Cross-lane sums without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32: an LDS instruction (address VGPR, the
+// LDS counter, ~100 cycles of latency in a dependent chain) -- three rounds of four of them per tile were worth 20 % of the ZI D
+// update (profiles/r06_zi_row_ablations.txt).  gfx950 does the same moves in the vector ALU:
+//   lane ^ 8    row_ror:8 inside each row of 16 lanes, folded into the addition (v_add_f32_dpp)
+//   lane ^ 16   v_permlane16_swap_b32: {x, x} -> {rows 0 0 2 2, rows 1 1 3 3}; their sum is x[l] + x[l ^ 16]
+//   lane ^ 32   v_permlane32_swap_b32: {x, x} -> {lower half twice, upper half twice}
+// (b is made an OPAQUE copy of a -- a one-instruction asm the optimiser cannot see through: with both operands the same SSA value
+//  __builtin_amdgcn_permlane16_swap / 32_swap of ROCm 7.2's hipcc returns its first result twice (v_add_f32 v2, v2, v2 after the
+//  swap).  The builtin, not inline assembly, issues the swap: the compiler then inserts the wait states of the gfx950 hazards
+//  around it itself -- a hand-written swap inside an asm string corrupted the 16-byte stores issued just before it.)
+typedef unsigned oriana_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap_rows16(uint32_t &a, uint32_t &b) {
+    const oriana_u2v r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r.x; b = r.y;
+}
+__device__ __forceinline__ void swap_halves32(uint32_t &a, uint32_t &b) {
+    const oriana_u2v r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r.x; b = r.y;
+}
+// (the s_nop 1 after the move: "VALU write of a swap operand -> v_permlane*_swap reads it" needs two wait states, and the
+//  compiler's hazard recogniser does not look inside an asm string)
+__device__ __forceinline__ uint32_t opaque_copy(uint32_t a) { uint32_t b; asm("v_mov_b32 %0, %1\n\ts_nop 1" : "=v"(b) : "v"(a)); return b; }
+__device__ __forceinline__ float add_xor8(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float add_xor16(float v) {
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+    swap_rows16(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float add_xor32(float v) {
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+    swap_halves32(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// sum over the lanes with the same lane % 8 (the eight 8-lane groups of a wave), in every lane
+__device__ __forceinline__ float sum_mod8(float v) { return add_xor32(add_xor16(add_xor8(v))); }
+
+// max / bitwise OR over aligned groups of LPR lanes (8, 16, 32, 64), in every lane of the group: DPP inside a row of 16,
+// v_permlane16_swap / v_permlane32_swap across rows -- no LDS instruction (k_gamma_update_vec: one reduction per row of cells)
+template <int LPR>
+__device__ __forceinline__ float lanes_max(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    if (LPR >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
+    if (LPR >= 32) {
+        uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+        swap_rows16(a, b);
+        v = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    }
+    if (LPR >= 64) {
+        uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+        swap_halves32(a, b);
+        v = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    }
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ uint32_t lanes_or(uint32_t v) {
+    v |= dpp_u32<0xB1>(v);
+    v |= dpp_u32<0x4E>(v);
+    v |= dpp_u32<0x141>(v);
+    if (LPR >= 16) v |= dpp_u32<0x140>(v);
+    if (LPR >= 32) { uint32_t b = opaque_copy(v); swap_rows16(v, b); v |= b; }
+    if (LPR >= 64) { uint32_t b = opaque_copy(v); swap_halves32(v, b); v |= b; }
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;

@@ -265,11 +265,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void k_dropout_sweep(float 
                 }
             }
             if (colsum) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-                    csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-                }
+                csum.x = sum_mod8(csum.x); csum.y = sum_mod8(csum.y); csum.z = sum_mod8(csum.z); csum.w = sum_mod8(csum.w);
                 if (lane < 8) *reinterpret_cast<f4v *>(lds + L.cs + (par * 4 + w) * 32 + gq) = csum;
             }
         }
@@ -753,11 +749,7 @@ __global__ __launch_bounds__(256, 2) void k_dropout_sweep_b16(float *__restrict_
                 }
             }
             if (colsum) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-                    csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-                }
+                csum.x = sum_mod8(csum.x); csum.y = sum_mod8(csum.y); csum.z = sum_mod8(csum.z); csum.w = sum_mod8(csum.w);
                 if (lane < 8) *reinterpret_cast<f4v *>(csb + (par * 4 + w) * 32 + gq) = csum;
             }
         }

@@ -337,11 +337,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                     cs4 = tq[1] * (8 < rleft ? 1.f : 0.f) + cs4;
                     cs4 = tq[2] * (16 < rleft ? 1.f : 0.f) + cs4;
                     cs4 = tq[3] * (24 < rleft ? 1.f : 0.f) + cs4;
-#pragma unroll
-                    for (int o = 8; o < 64; o <<= 1) {
-                        cs4.x += __shfl_xor(cs4.x, o, 64); cs4.y += __shfl_xor(cs4.y, o, 64);
-                        cs4.z += __shfl_xor(cs4.z, o, 64); cs4.w += __shfl_xor(cs4.w, o, 64);
-                    }
+                    cs4.x = sum_mod8(cs4.x); cs4.y = sum_mod8(cs4.y); cs4.z = sum_mod8(cs4.z); cs4.w = sum_mod8(cs4.w);
                     *reinterpret_cast<f4v *>(csb + (par * NW + w) * 32 + gq) = cs4;      // (eight lanes, the same value)
                 } else {
                     const int vv = it - 18;

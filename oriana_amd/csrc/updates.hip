@@ -295,9 +295,9 @@ __global__ __launch_bounds__(256) void k_gamma_update_vec(const GuVecArgs A) {
             bool bad = false;
             #pragma unroll
             for (int v = 0; v < VEC; ++v) { if (el[v] != el[v]) bad = true; mx = fmaxf(mx, el[v]); }
-            int badi = bad ? 1 : 0;
-            #pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); badi |= __shfl_xor(badi, o, 64); }
+            static_assert(LPR >= 8, "lanes_max / lanes_or reduce over groups of at least 8 lanes");
+            mx = lanes_max<LPR>(mx);                           // (DPP / permlane swaps: ten ds_bpermute per row pair before)
+            const int badi = (int)lanes_or<LPR>(bad ? 1u : 0u);
             if (in) {
                 float fu[VEC];
                 #pragma unroll

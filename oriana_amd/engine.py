@@ -713,15 +713,21 @@ def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None, clear=None):
          ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), stream_ptr())
 
 
-_COL_F64 = os.environ.get('ORIANA_COL_F64') == '1'     # analysis runs (tools/parity_report.py): float64 accumulators, one rounding
+# ORIANA_LOG_SUMS=compensated: the centred log sums of the sparse models (the second sum of the dual column pass, Kp <= 64) in a
+# two-float accumulator -- p_s as close to exact as the reference's own loop, for a slower column pass
+LOG_SUMS_COMPENSATED = os.environ.get('ORIANA_LOG_SUMS', '') == 'compensated'
+
+# analysis runs (tools/parity_report.py): float64 accumulators and one rounding for the per-gene sums -- '1': all of them, 'log': the
+# centred log sums of the sparse models only (C2), 'zj': everything but those
+_COL_F64 = os.environ.get('ORIANA_COL_F64', '')
 
 
-def col_pass(ct, s_cs, G, C, K, C_ptr=None):
+def col_pass(ct, s_cs, G, C, K, C_ptr=None, what='zj'):
     """C += s G over the sliced layout.  `C_ptr`: device address of the first gene row of the sliced layout inside C
-    (hybrid layouts: gd rows in)."""
+    (hybrid layouts: gd rows in).  `what`: 'zj' (the per-gene sums of gap.py:80) or 'log' (the centred log sums)."""
     w = ct.col_work_for(K)
     Cp = ptr(C) if C_ptr is None else C_ptr
-    if _COL_F64:
+    if _COL_F64 == '1' or _COL_F64 == what:
         call('oriana_col_pass_f64acc', ct.sparse_struct, ptr(s_cs), ptr(G), Cp, K, stream_ptr())
         return
     if DETERMINISTIC and w is not None:
@@ -741,12 +747,12 @@ def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K, goff=0):
     the two factor images do not fit in LDS (or in the deterministic debug mode): the caller runs two column passes.
     `goff`: byte offset of the sliced part's first gene row inside C1 / C2 (hybrid layouts)."""
     if DETERMINISTIC or not _FUSE_SPARSE_COLS or _COL_F64:
-        return False
+        return False                        # (the analysis mode runs the two sums as two passes)
     w = ct.col_work_width(1)
     if w is None:
         return False
-    rc = _lib.load().oriana_col_pass_dual(ct.sparse_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1) + goff, ptr(C2) + goff, K, ptr(w),
-                                          w.shape[0], stream_ptr())
+    f = _lib.load().oriana_col_pass_dual_compensated if LOG_SUMS_COMPENSATED else _lib.load().oriana_col_pass_dual
+    rc = f(ct.sparse_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1) + goff, ptr(C2) + goff, K, ptr(w), w.shape[0], stream_ptr())
     if rc not in (0, -2):
         raise _lib.OrianaHipError('oriana_col_pass_dual failed with code %d' % rc)
     return rc == 0
@@ -971,7 +977,7 @@ def zq(ws, Z_i, Z_j, Z_log, log_U_hat, log_V_hat, S_tilde=None, S_hat=None, dq=N
                 dense_cols(ws.FU, ws.C)
         if not dual_done and have_sliced:
             with _span(ws, 'col_pass_log'):
-                col_pass(ct, s_log, G2, C2, K, C_ptr=ptr(C2) + goff)
+                col_pass(ct, s_log, G2, C2, K, C_ptr=ptr(C2) + goff, what='log')
         if dn is not None:
             dense_cols(G2, C2)
         call('oriana_finalize_zlog', ptr(Z_log), ptr(ws.FV), ptr(C2), ptr(ws.C), ptr(log_V_hat), ws.center_ptr, ptr(ct.col_perm), m, K, st)

@@ -465,16 +465,16 @@ def measure(args, workload, steps, warmup, world, rank, dev, np, torch, dist, cp
                          'fixup_ms': ks.get('fixup', 0.0),
                          # the responsibility kernels are bound on the CU side: VALU issue + LDS-return
                          # traffic, not HBM -- the same launches against those rates
-                         # what binds each kernel of the pass (counters under profiles/r03_*)
+                         # what binds each kernel of the pass (DESIGN_HISTORY.md section 10; counters under profiles/r03_*)
                          'limiter_per_kernel': {k: v for k, v in {
                              'row_pass': 'VALU issue + LDS return port (two lanes per row, 400 B of K-vector per slot)',
-                             'col_pass': 'VALU issue + LDS return port (issue-bound: masking the padding slots\' reads leaves the time unchanged, DESIGN.md 10 j)',
+                             'col_pass': 'VALU issue + LDS return port (issue-bound: masking the padding slots\' reads leaves the time unchanged, DESIGN_HISTORY.md 10 j)',
                              'dense_row': 'matrix pipe + LDS operand reads + VALU (splits, s = x / den), which add up rather than overlap',
                              'dense_col': 'matrix pipe + LDS operand reads + VALU (splits of s); HBM read of s (4 B per entry)',
                              'dense_images': 'HBM (split operand images, (n + gd) K values)', 'fixup': 'rare (exact slow path)'}.items() if k in ks},
                          'limiter': ('valu+lds (see DESIGN.md section 4)' if not model.zi else
                                      'responsibility kernels: valu+lds (DESIGN.md section 4); dense ZI kernels: valu + matrix '
-                                     'cores, which barely overlap (DESIGN.md section 10h)'),
+                                     'cores, which barely overlap (DESIGN_HISTORY.md section 10h)'),
                          'valu': {'achieved': useful_tflops, 'peak': VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': useful_tflops / VALU_PEAK_TFLOPS},
                          'lds': {'achieved': useful_lds_gbs, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',

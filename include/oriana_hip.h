@@ -261,12 +261,6 @@ int oriana_col_pass(const oriana_counts *cm, const float *s_cs,
  * Returns ORIANA_EKRANGE when two images do not fit (Kp > 64): call oriana_col_pass twice then. */
 int oriana_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,
                          float *C2, int64_t K, const int32_t *work, int64_t nwork, void *stream);
-/* [r6] oriana_col_pass_dual with the SECOND sum (C2) in a two-float accumulator (t = fma(s, g, hi); lo += fma(s, g, hi - t);
- * hi = t): for the centred log sums of the sparse models (sparse_gap.py:97 as oriana_finalize_zlog combines it), whose terms
- * carry both signs -- p_s then sits as close to its exact value as the reference's own float32 loop (2.0e-6 instead of 7.1e-6
- * on the goldens) for 3 more packed instructions per pair of elements of the second image.  Same arguments, same return codes. */
-int oriana_col_pass_dual_compensated(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,
-                                     float *C2, int64_t K, const int32_t *work, int64_t nwork, void *stream);
 /* [r6] Analysis entry, not on the path of a sweep: the same sums with float64 accumulators in a fixed order and one rounding to
  * float32 at the end (C += f32(sum_i s_ij G_i)): the most a compensated accumulation of the float32 kernels could reach
  * (tools/parity_report.py: ORIANA_COL_F64=1 routes the per-gene sums of the sparse models' log sums through it). */

@@ -78,7 +78,6 @@ _SIGS = {
     'oriana_col_pass': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_dual': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_f64acc': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P]),
-    'oriana_col_pass_dual_compensated': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'oriana_col_pass_det_scratch_bytes': (c_int64, [_I, _I]),
     'oriana_col_pass_det': (c_int, [ctypes.POINTER(OrianaCounts), _P, _P, _P, _I, _P, _I, _P, _P]),
     'oriana_dense_supported': (c_int, [_I]),

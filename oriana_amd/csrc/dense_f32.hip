@@ -819,7 +819,7 @@ static int64_t pick_splits(int64_t blocks, int64_t max_splits) {
 // (pi_d >= 1: p_d = 1 - 1e-10, 1 in float32)
 // [r5] lgs (may be NULL): the same as -logit * log2(e) -- the form dn::k_zi_row takes: its sigmoid is
 // 1 / (1 + exp2(fma(Lambda, log2 e, lgs))), one fused multiply-add where the subtraction and the scaling were two instructions
-// per entry (floating-point vector work beside matrix instructions is the dear kind on this part, DESIGN.md 10 i)
+// per entry (floating-point vector work beside matrix instructions is the dear kind on this part, DESIGN_HISTORY.md 10 i)
 // [r6] flo (with lgs): the floor dn::k_zi_row ADDS to its sigmoid -- 1e-10 where pi_d <= 0 (there lgs = +inf makes the sigmoid
 // +0: the column override of zigap.py:133 as one addition), 0 elsewhere.
 __global__ void k_logit_f32(float *__restrict__ lg, float *__restrict__ lgs, float *__restrict__ flo,

@@ -67,6 +67,9 @@ struct Cfg {
     static constexpr int PV_RAW = P1 + P2 + PT;                          // gene side: both images + tail
     static constexpr int PU_RAW = P2 + PT;                               // cell side: second image + tail
     static constexpr int PV = (PV_RAW + NW * 64 - 1) / (NW * 64) * (NW * 64);   // every wave copies the same number of pieces
+    // [r6] the gene-side copy of dn::k_zi_row: always two 64-piece slots of padding behind the images (the tile's non-zero flags
+    // and logits ride there; KC = 4 without tail had none)
+    static constexpr int PVZ = (PV_RAW + 2 * 64 + NW * 64 - 1) / (NW * 64) * (NW * 64);
     static constexpr int PU = (PU_RAW + NW * 64 - 1) / (NW * 64) * (NW * 64);
     static constexpr int KM = 16 * KC;                                    // factors on the matrix core
 };

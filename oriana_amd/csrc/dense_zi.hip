@@ -13,6 +13,7 @@
 // float32 matrix instruction for K > 100 or a gene count that is not a multiple of 4 (16-byte row pieces).
 #include "dense_tiles.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace oriana {
 namespace dn {
@@ -24,7 +25,7 @@ template <int KC, int TAIL, bool BOTH>
 __global__ __launch_bounds__(512) void k_zi_images(u4v *__restrict__ img, const double *__restrict__ F1,
                                                    const double *__restrict__ F2, int64_t rows, int K) {
     using C = Cfg<KC, TAIL>;
-    constexpr int PIMG = BOTH ? C::PV : C::PU;
+    constexpr int PIMG = BOTH ? C::PVZ : C::PU;
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     u4v *dst0 = img + (int64_t)blockIdx.x * PIMG;
@@ -99,15 +100,15 @@ __device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const 
     // clamped lane fetches belongs to padding cells / genes, whose values are neither stored nor summed.
     using C = Cfg<KC, TAIL>;
     constexpr int SLOT0 = C::PV_RAW / 64;
-    static_assert(C::PV_RAW % 64 == 0 && C::PV / 64 >= SLOT0 + 2, "the image padding holds the flag and logit pieces");
+    static_assert(C::PV_RAW % 64 == 0 && C::PVZ / 64 >= SLOT0 + 2, "the image padding holds the flag and logit pieces");
     const int64_t j0 = (int64_t)gt * 32;
-    const char *ibase = reinterpret_cast<const char *>(imgV + (int64_t)gt * C::PV);
+    const char *ibase = reinterpret_cast<const char *>(imgV + (int64_t)gt * C::PVZ);
     // (the flag array covers whole work-groups of 8 cell tiles: no clamp; lane l copies piece l % 8 of wave l / 8)
     const char *mbase = reinterpret_cast<const char *>(nztiles + (ct_blk0 * ngt + gt) * 32);
     const char *lbase = reinterpret_cast<const char *>(lgit + j0);
     const int jlim = (int)((m - 4 - j0 < 252) ? m - 4 - j0 : 252);          // last whole 16-byte piece of the row (>= 0)
 #pragma unroll
-    for (int p = 0; p < C::PV / (NW * 64); ++p) {
+    for (int p = 0; p < C::PVZ / (NW * 64); ++p) {
         const int slot = p * NW + w;                                       // wave-uniform
         const char *base = ibase;
         uint32_t voff = (uint32_t)(slot * 64 + lane) * 16u;                // an image piece (or its padding: harmless)
@@ -125,7 +126,7 @@ __device__ __forceinline__ void zi_tile_dma(const u4v *__restrict__ imgV, const 
 }
 
 template <int KC, int TAIL>
-constexpr int zi_row_lds_bytes() { return 3 * Cfg<KC, TAIL>::PV * 16 + NW * 32 * 32 * 4 + 2 * NW * 32 * 4; }
+constexpr int zi_row_lds_bytes() { return 3 * Cfg<KC, TAIL>::PVZ * 16 + NW * 32 * 32 * 4 + 2 * NW * 32 * 4; }
 
 template <int KC, int TAIL>
 __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const double *__restrict__ U,
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     u4v *img = ldsq;                                                      // [3][PV]
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *T = reinterpret_cast<float *>(ldsq + 3 * C::PV) + w * 32 * 32;  // [wave][32 cells][32 genes], 16-byte chunks swizzled
-    float *csb = reinterpret_cast<float *>(ldsq + 3 * C::PV) + NW * 32 * 32;   // [2][8 waves][32 genes]
+    float *T = reinterpret_cast<float *>(ldsq + 3 * C::PVZ) + w * 32 * 32;  // [wave][32 cells][32 genes], 16-byte chunks swizzled
+    float *csb = reinterpret_cast<float *>(ldsq + 3 * C::PVZ) + NW * 32 * 32;   // [2][8 waves][32 genes]
     const int64_t ct_blk0 = (int64_t)blockIdx.x * NW;
     const int64_t ct = ct_blk0 + w;                                        // this wave's cell tile
     const int64_t i = ct * 32 + c;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     };
 
     zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img, gt0, ct_blk0, ngt, m, w, lane);
-    zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + C::PV, (gt0 + 1 < gt1) ? gt0 + 1 : gt0, ct_blk0, ngt, m, w, lane);
+    zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + C::PVZ, (gt0 + 1 < gt1) ? gt0 + 1 : gt0, ct_blk0, ngt, m, w, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f16v dn = phase_D(img);              // Lambda^T of tile gt0
@@ -243,15 +244,15 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     constexpr int NB = NT * 12;                                            // ... of the second one
     for (int gt = gt0; gt < gt1; ++gt) {
         const int bufn = (buf == 2) ? 0 : buf + 1, bufnn = (buf == 0) ? 2 : buf - 1;
-        const u4v *im1 = img + bufn * C::PV;                               // tile gt + 1: first product
-        const u4v *im0 = img + buf * C::PV;                                // tile gt: second product, masks, logits
+        const u4v *im1 = img + bufn * C::PVZ;                               // tile gt + 1: first product
+        const u4v *im0 = img + buf * C::PVZ;                                // tile gt: second product, masks, logits
         const int64_t j0 = (int64_t)gt * 32;
         if (gt > gt0) colsum_flush(gt - 1, par ^ 1);
         // The image, masks and logits of tile gt + 2 go out into the buffer tile gt - 1 has left: in the middle of the
         // matrix work for the long loops (item 16 below; measured at 100k x 20k: 5.10 against 5.26 ms at K = 100, 4.38 / 4.46
         // at K = 80), here at the top for KC <= 3 (3.45 against 3.78 ms at K = 48)
         if (DMA_TOP)
-            zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, ngt, m,
+            zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + bufnn * C::PVZ, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, ngt, m,
                                   w, lane);
         u4v A0[2], A1, A2;
         A2 = im1[2 * 64 + lane]; A0[0] = im1[0 * 64 + lane]; A1 = im1[1 * 64 + lane];
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
 #pragma unroll
                     for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const f4v *>(Tr + 8 * q * 32);
                     if (!DMA_TOP)
-                        zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + bufnn * C::PV, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, ngt, m,
+                        zi_tile_dma<KC, TAIL>(imgV, nztiles, lgit, mpad, img + bufnn * C::PVZ, (gt + 2 < gt1) ? gt + 2 : gt1 - 1, ct_blk0, ngt, m,
                                   w, lane);
                 } else if (it == 17) {
                     // D_hat rows out
@@ -596,6 +597,7 @@ static int64_t zi_pick_splits(int64_t blocks, int64_t max_splits) {
         else if (KC_ == 5 && TL_ == 1) { CALL(5, 1); }                        \
         else if (KC_ == 5 && TL_ == 0) { CALL(5, 0); }                        \
         else if (KC_ == 4 && TL_ == 1) { CALL(4, 1); }                        \
+        else if (KC_ == 4 && TL_ == 0) { CALL(4, 0); }                        \
         else if (KC_ == 3 && TL_ == 1) { CALL(3, 1); }                        \
         else if (KC_ == 3 && TL_ == 0) { CALL(3, 0); }                        \
         else return ORIANA_EKRANGE;                                           \
@@ -611,7 +613,7 @@ static bool zi_cfg(int64_t K, int *kc, int *tl) {
     const int64_t Kp = oriana_kpad(K);
     if (K < zi_min_k() || Kp == 0 || Kp > 100 || (Kp % 16 != 0 && Kp % 16 != 4)) return false;
     *kc = (int)(Kp / 16); *tl = (Kp % 16 == 4) ? 1 : 0;
-    return *kc >= 3 && *kc <= 6 && !(*kc == 4 && *tl == 0);               // Kp = 48 .. 100 (Kp = 64: the image has no padding)
+    return *kc >= 3 && *kc <= 6 && !(*kc == 4 && *tl == 0);               // Kp = 48 .. 100 (Kp = 64: dense_f32.hip, measured)
 }
 
 bool zi_supported(int64_t m, int64_t K) {                                  // the D update
@@ -619,13 +621,24 @@ bool zi_supported(int64_t m, int64_t K) {                                  // th
     return (m % 4) == 0 && zi_cfg(K, &kc, &tl);
 }
 
+// [r6] D_hat^T W below K = 65: Kp = 36 and 52 (K = 50: configs[2]) take the NEXT whole chunk of 16 with zero-padded factors instead
+// of the tail of four -- k_zi_col<4, 0> 1.50 ms against 1.67 ms for k_dt_times_factor_b16 inside the configs[2] sweep (the D update
+// itself is faster WITH the tail: 3.49 against 3.94 ms; profiles/r06_zi_k52_ab.txt)
+static bool zi_cfg_dt(int64_t K, int *kc, int *tl) {
+    const int64_t Kp = oriana_kpad(K);
+    if (K < zi_min_k() || Kp == 0 || Kp > 100 || (Kp % 16 != 0 && Kp % 16 != 4)) return false;
+    *kc = (int)(Kp / 16); *tl = (Kp % 16 == 4) ? 1 : 0;
+    if (*tl && *kc <= 3) { *kc += 1; *tl = 0; }
+    return *kc >= 3 && *kc <= 6;
+}
+
 bool zi_dt_supported(int64_t m, int64_t K) {                               // D_hat^T W
     int kc, tl;
-    return (m % 4) == 0 && zi_cfg(K, &kc, &tl) && (K > 64 || tl == 0);
+    return (m % 4) == 0 && zi_cfg_dt(K, &kc, &tl) && (K > 64 || tl == 0);
 }
 
 // floats of scratch for the gene-side images of m genes / the cell-side images of n cells (largest configuration)
-int64_t zi_sweep_image_floats(int64_t m) { return ((m + 31) / 32) * (int64_t)Cfg<6, 1>::PV * 4; }
+int64_t zi_sweep_image_floats(int64_t m) { return ((m + 31) / 32) * (int64_t)Cfg<6, 1>::PVZ * 4; }
 int64_t zi_dt_image_floats(int64_t n) { return ((n + 31) / 32 + 2) * (int64_t)Cfg<6, 1>::PU * 4; }
 
 // [r6] The non-zero flags of a (cell tile, gene tile) pair in the order k_zi_row's lanes hold their values: 64 x 16 bits
@@ -697,7 +710,7 @@ int zi_sweep(float *D_hat, const double *U, const double *V, const float *lgit, 
 
 int zi_dt(double *out, const float *D, const double *W, float *scratch, int64_t n, int64_t m, int K, hipStream_t st) {
     int kc, tl;
-    if (!zi_dt_supported(m, K) || !zi_cfg(K, &kc, &tl)) return ORIANA_EKRANGE;
+    if (!zi_dt_supported(m, K) || !zi_cfg_dt(K, &kc, &tl)) return ORIANA_EKRANGE;
     if ((reinterpret_cast<uintptr_t>(D) & 15) != 0) return ORIANA_EKRANGE;   // 16-byte row pieces: the caller falls back
     const int ngt = (int)((m + 31) / 32);
     const int64_t nct = (n + 31) / 32;

@@ -687,7 +687,7 @@ extern "C" int oriana_col_pass_f64acc(const oriana_counts *cm, const float *s_cs
 }
 
 // two images, one column tile per work item (work list of width 1)
-template <int G, int T4, int TAIL, bool COMP = false>
+template <int G, int T4, int TAIL>
 static int launch_col_pass_dual(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2, float *C1,
                                 float *C2, const int32_t *work, int64_t nwork, hipStream_t s) {
     constexpr int T4c = (G == 4) ? T4 : 1, TLc = (G == 4) ? TAIL : 0;
@@ -697,7 +697,7 @@ static int launch_col_pass_dual(const oriana_counts *cm, const float *s_cs, cons
     if (G != 4 || Im::DUP || 2 * Im::bytes() > (size_t)LDS_BUDGET) return ORIANA_EKRANGE;
     if (nwork <= 0) return 0;
     constexpr bool OK = (G == 4) && !Im::DUP;
-    auto kern = k_col_pass2<T4c, OK ? TLc : 0, OK, OK && COMP>;
+    auto kern = k_col_pass2<T4c, OK ? TLc : 0, OK>;
     const size_t lb = 2 * Im::bytes();
     int rc = set_lds(kern, lb);
     if (rc) return rc;
@@ -716,21 +716,6 @@ extern "C" int oriana_col_pass_dual(const oriana_counts *cm, const float *s_cs, 
     if (!G1 || !G2 || !C1 || !C2 || !s_cs || !work || nwork < 0) return ORIANA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
 #define CALL(G, T, L) return launch_col_pass_dual<G, T, L>(cm, s_cs, G1, G2, C1, C2, work, nwork, s)
-    ORIANA_FOR_CFG(cfg, CALL);
-#undef CALL
-    return 0;
-}
-
-// [r6] the same with the second sum in a two-float accumulator (k_col_pass2<.., COMP>: the centred log sums of the sparse models)
-extern "C" int oriana_col_pass_dual_compensated(const oriana_counts *cm, const float *s_cs, const float *G1, const float *G2,
-                                                float *C1, float *C2, int64_t K, const int32_t *work, int64_t nwork, void *stream) {
-    if (!counts_ok(cm) || K <= 0) return ORIANA_EINVAL;
-    KCfg cfg;
-    if (!pick_cfg(K, &cfg)) return ORIANA_EKRANGE;
-    if (cm->n == 0 || cm->m == 0) return 0;
-    if (!G1 || !G2 || !C1 || !C2 || !s_cs || !work || nwork < 0) return ORIANA_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-#define CALL(G, T, L) return launch_col_pass_dual<G, T, L, true>(cm, s_cs, G1, G2, C1, C2, work, nwork, s)
     ORIANA_FOR_CFG(cfg, CALL);
 #undef CALL
     return 0;

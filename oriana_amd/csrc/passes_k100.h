@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512) void k_row_pass_k100(oriana_counts cm, const f
 
 // ---- the same image read by FOUR lanes per row (column pass, k_col_pass2 below) ----------------------
 // (a 1024-thread group leaves 128 registers per lane: two lanes per column would keep only two of the twelve reads
-// of a step in flight -- measured)
+// of a step in flight -- measured, DESIGN_HISTORY.md section 8)
 __device__ __forceinline__ int quad_class(int lane) { const int Q = lane >> 2; return ((Q & 1) << 1) | ((Q >> 1) & 1); }
 __device__ __forceinline__ int gchunk4(int lane, int t) {
     const int a = quad_class(lane), q = lane & 3;
@@ -299,14 +299,7 @@ struct ColImage {
 // DUAL: ONE column tile per work item and TWO images (Gm, Gm2) of the row block side by side in LDS: both products
 // C += s Gm and C2 += s Gm2 from one walk over the slice's stream (the sparse models' per-gene sums and log sums,
 // sparse_gap.py:96-97; Kp <= 64: two images fit).
-// [r6] COMP (DUAL only): the SECOND sum -- the centred log sums of the sparse models, whose terms s G2 carry both signs -- in a
-// two-float accumulator: t = fma(s, v, hi); lo += fma(s, v, hi - t); hi = t  (hi - t is exact whenever the term is not larger
-// than the running sum, and then the second fma returns the rounding error of the first exactly).  Accumulated in plain float32
-// those sums are what keeps p_s 3.6 x further from its exact value than the reference's own arithmetic (7.1e-6 against 2.0e-6 on
-// the goldens; with this 2.0e-6: profiles/r06_parity_log_sums.json).  Two extra packed instructions and one packed addition per
-// pair of elements of the second image; ORIANA_LOG_SUMS=compensated (engine.py) selects it -- it is NOT the default, for its cost
-// (DESIGN.md section 8).
-template <int T4, int TAIL, bool DUAL, bool COMP = false>
+template <int T4, int TAIL, bool DUAL>
 __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const float *__restrict__ s_cs,
                                                     const float *__restrict__ Gm, float *__restrict__ C,
                                                     const int32_t *__restrict__ work, int64_t rb_per_band,
@@ -336,13 +329,10 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
     int lidx[T4];
     #pragma unroll
     for (int t = 0; t < T4; ++t) lidx[t] = Im::lidx(lane, t);
-    static_assert(!COMP || DUAL, "the compensated accumulator serves the second image of the dual pass");
-    f4 accA[T4], accB[T4], lowB[COMP ? T4 : 1];
-    float actA = 0.f, actB = 0.f, lowtB = 0.f;
+    f4 accA[T4], accB[T4];
+    float actA = 0.f, actB = 0.f;
     #pragma unroll
     for (int t = 0; t < T4; ++t) { accA[t] = f4{0.f, 0.f, 0.f, 0.f}; accB[t] = f4{0.f, 0.f, 0.f, 0.f}; }
-    #pragma unroll
-    for (int t = 0; t < (COMP ? T4 : 1); ++t) lowB[t] = f4{0.f, 0.f, 0.f, 0.f};
 
     // stream of one slice: (s, row index) per slot; the loads are unconditional -- an index past the slice's end is
     // clamped, and with an empty slice it reads (and discards) slots that still lie inside the tile's region, which
@@ -393,25 +383,14 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
                         accA[tt].xy = __builtin_elementwise_fma(ss, v.xy, accA[tt].xy);               \
                         accA[tt].zw = __builtin_elementwise_fma(ss, v.zw, accA[tt].zw);               \
                         const f4 v2 = vrow[IMG4 + lidx[tt]];                                          \
-                        if (COMP) {                                                                   \
-                            const f2 t01 = __builtin_elementwise_fma(ss, v2.xy, accB[tt].xy);         \
-                            const f2 t23 = __builtin_elementwise_fma(ss, v2.zw, accB[tt].zw);         \
-                            lowB[tt].xy += __builtin_elementwise_fma(ss, v2.xy, accB[tt].xy - t01);   \
-                            lowB[tt].zw += __builtin_elementwise_fma(ss, v2.zw, accB[tt].zw - t23);   \
-                            accB[tt].xy = t01; accB[tt].zw = t23;                                     \
-                        } else {                                                                      \
-                            accB[tt].xy = __builtin_elementwise_fma(ss, v2.xy, accB[tt].xy);          \
-                            accB[tt].zw = __builtin_elementwise_fma(ss, v2.zw, accB[tt].zw);          \
-                        }                                                                             \
+                        accB[tt].xy = __builtin_elementwise_fma(ss, v2.xy, accB[tt].xy);              \
+                        accB[tt].zw = __builtin_elementwise_fma(ss, v2.zw, accB[tt].zw);              \
                     }                                                                                 \
                     if (TAIL) {                                                                       \
                         actA = fmaf(s, tails[r * Im::TSTR + toff], actA);                             \
-                        const float vt2 = tails[IMG4 * 4 + r * Im::TSTR + toff];                      \
-                        if (COMP) { const float tt2 = fmaf(s, vt2, actB); lowtB += fmaf(s, vt2, actB - tt2); actB = tt2; } \
-                        else actB = fmaf(s, vt2, actB);                                               \
+                        actB = fmaf(s, tails[IMG4 * 4 + r * Im::TSTR + toff], actB);                  \
                     }                                                                                 \
                     _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(accA[tt]), "+v"(accB[tt]));  \
-                    if (COMP) { _Pragma("unroll") for (int tt = 0; tt < T4; ++tt) asm volatile("" : "+v"(lowB[tt])); }    \
                     asm volatile("" : "+v"(svc), "+v"(rvc));                                          \
                 }
 #define ORIANA_COL_RUN4D(ST)                                                                          \
@@ -483,11 +462,6 @@ __global__ __launch_bounds__(1024) void k_col_pass2(oriana_counts cm, const floa
 #undef ORIANA_COL_STEP4D
 #undef ORIANA_COL_RUN4
 #undef ORIANA_COL_STEP4
-    if (COMP) {
-        #pragma unroll
-        for (int t = 0; t < T4; ++t) accB[t] += lowB[t];
-        actB += lowtB;
-    }
     const int cl = sl * 16 + (lane >> 2);
     const bool plain = Cpart != nullptr;
     float *ldsf = reinterpret_cast<float *>(lds);

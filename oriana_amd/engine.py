@@ -178,7 +178,7 @@ class CountTiles:
         items = np.empty((max(cap, 1), 3), dtype=np.int32)
         n_items = ctypes.c_int64(0)
         # (the pair's price: the maximum of the two slices -- with the constants fitted to it the sum measured 2.6 % slower on
-        #  the column pass at C4, DESIGN.md 10 j; re-cut to whole rounds of the chip, DESIGN.md 10 l)
+        #  the column pass at C4, DESIGN_HISTORY.md 10 j; re-cut to whole rounds of the chip, DESIGN_HISTORY.md 10 l)
         call('oriana_plan_col_work', nit.ctypes.data, self.nrb, self.ncb, int(width), int(lib.oriana_device_cus()),
              int(target_items or 0), 1, 0, items.ctypes.data, cap, ctypes.addressof(n_items))
         return torch.from_numpy(items[:int(n_items.value)].copy()).to(self.device).contiguous()
@@ -199,7 +199,7 @@ class CountTiles:
         self.gene_tile_cost = None
         if self.tile_rslots is not None and self.nrb * self.ncb > 0:
             per = self.tile_rslots[:self.nrb * self.ncb].view(self.nrb, self.ncb).to(torch.float64).mean(dim=0) / (16 * 64)
-            stage = 2.0                      # (staging a tile's 256 factor rows, in slice iterations: flat between 0.5 and 4, DESIGN.md 10 l)
+            stage = 2.0                      # (staging a tile's 256 factor rows, in slice iterations: flat between 0.5 and 4, DESIGN_HISTORY.md 10 l)
             self.gene_tile_cost = np.ascontiguousarray((per + stage).cpu().numpy(), dtype=np.float64)
         self.tile_rslots = self.tile_cslots = None
         if self.gd and self.col_perm is None:
@@ -437,7 +437,7 @@ def dense_supported(K):
 
 
 # Default density threshold of the hybrid layout (FactorModel(dense_density='auto')): measured break-even of the
-# matrix-core evaluation against the sliced layout on the benchmark's density profile.
+# matrix-core evaluation against the sliced layout on the benchmark's density profile (DESIGN_HISTORY.md section 10).
 DENSE_DENSITY_DEFAULT = 0.2
 
 
@@ -713,10 +713,6 @@ def factor_prep_pair(ws, log_U_hat, log_V_hat, mask_v=None, clear=None):
          ptr(ct.col_perm), ct.n, ct.m, ws.K, ptr(ws.stats), stream_ptr())
 
 
-# ORIANA_LOG_SUMS=compensated: the centred log sums of the sparse models (the second sum of the dual column pass, Kp <= 64) in a
-# two-float accumulator -- p_s as close to exact as the reference's own loop, for a slower column pass
-LOG_SUMS_COMPENSATED = os.environ.get('ORIANA_LOG_SUMS', '') == 'compensated'
-
 # analysis runs (tools/parity_report.py): float64 accumulators and one rounding for the per-gene sums -- '1': all of them, 'log': the
 # centred log sums of the sparse models only (C2), 'zj': everything but those
 _COL_F64 = os.environ.get('ORIANA_COL_F64', '')
@@ -751,8 +747,8 @@ def col_pass_dual(ct, s_cs, G1, G2, C1, C2, K, goff=0):
     w = ct.col_work_width(1)
     if w is None:
         return False
-    f = _lib.load().oriana_col_pass_dual_compensated if LOG_SUMS_COMPENSATED else _lib.load().oriana_col_pass_dual
-    rc = f(ct.sparse_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1) + goff, ptr(C2) + goff, K, ptr(w), w.shape[0], stream_ptr())
+    rc = _lib.load().oriana_col_pass_dual(ct.sparse_struct, ptr(s_cs), ptr(G1), ptr(G2), ptr(C1) + goff, ptr(C2) + goff, K, ptr(w),
+                                          w.shape[0], stream_ptr())
     if rc not in (0, -2):
         raise _lib.OrianaHipError('oriana_col_pass_dual failed with code %d' % rc)
     return rc == 0

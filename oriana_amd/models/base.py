@@ -63,7 +63,7 @@ class FactorModel:
     device : torch device (default cuda).  process_group : torch.distributed group for row sharding.
     reference_quirks : reproduce zigap.py:94 (``D_hat[i, k]``) -- see SURVEY.md 8(a) policy.
     dense_density : genes expressed in at least this share of the cells are evaluated densely on the bf16 matrix cores in
-        float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip).  Every model takes it:
+        float32-equivalent arithmetic (hybrid layout, csrc/dense_pass.hip; DESIGN_HISTORY.md section 10).  Every model takes it:
         inside the ZI models D_hat = 1 at every non-zero count, so their nest is the pCMF nest plus the D_hat[i, k] weight
         on the gene side; the sparse models' den runs against the masked FV image, their accumulation against FV * S_hat,
         their log sums through a second gene-side pass.  ``'auto'`` for the ZI / sparse models: the same threshold, but only

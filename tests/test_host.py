@@ -155,7 +155,7 @@ def test_hybrid_gene_order_rules():
 
 def test_hybrid_auto_threshold(monkeypatch):
     """'auto': the measured break-even for a factor count the dense kernels exist for and >= 2e8 entries; the
-    ORIANA_DENSE_DENSITY switch overrides the value or turns the layout off."""
+    ORIANA_DENSE_DENSITY switch overrides the value or turns the layout off (DESIGN_HISTORY.md section 10)."""
     from oriana_amd import engine
     monkeypatch.delenv('ORIANA_DENSE_DENSITY', raising=False)
     assert engine.auto_dense_density(1_000_000, 30_000, 100) == engine.DENSE_DENSITY_DEFAULT

@@ -1,6 +1,6 @@
 """Slot efficiency of the packed layout on the generator's data (CPU, no GPU): the shipped scheme (16-row slices of fixed
 rows, padded per tile; work-group waits for its slowest slice) against per-tile regrouping of the rows (sorted by their
-count in the tile) -- DESIGN.md section 10(e) -- and the share of non-zeros / lane time per density band of the genes."""
+count in the tile) -- DESIGN_HISTORY.md section 10(e) -- and the share of non-zeros / lane time per density band of the genes."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from oriana_amd.singlecell.generation import SyntheticCounts

@@ -1,6 +1,6 @@
 # -*- coding: utf-8 -*-
 """ZI-pCMF at configs[2] (100k x 20k, K = 50): flagged tiles, rejected rows and the row maxima of E[log U], E[log V] over the sweeps,
-then the pass timings of five more sweeps (DESIGN.md 10 m).  ORIANA_DEN_THRESHOLD=fixed: the constant threshold of round 3."""
+then the pass timings of five more sweeps (DESIGN_HISTORY.md 10 m).  ORIANA_DEN_THRESHOLD=fixed: the constant threshold of round 3."""
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from oriana_amd import engine

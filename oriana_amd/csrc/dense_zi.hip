@@ -26,6 +26,10 @@ __global__ __launch_bounds__(512) void k_zi_images(u4v *__restrict__ img, const 
                                                    const double *__restrict__ F2, int64_t rows, int K) {
     using C = Cfg<KC, TAIL>;
     constexpr int PIMG = BOTH ? C::PVZ : C::PU;
+    // [r6] D update with a tail that fits the last factor tile of the second product (KC = 3: factors 48..51 inside 32..63; KC = 5:
+    // 80..83 inside 64..95): the tail factors of V_next ride in that tile's image columns, which were zero -- the second product
+    // then needs no float32 4 x 4 x 1 instructions for them (k_zi_row: TIB)
+    constexpr int KM2 = (BOTH && TAIL && 32 * C::NT >= C::KM + 4) ? C::KM + 4 : C::KM;
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     u4v *dst0 = img + (int64_t)blockIdx.x * PIMG;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(512) void k_zi_images(u4v *__restrict__ img, const 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int64_t r = r0 + acc_row(8 * q + e, hh);
-                x[e] = (r < rows && kk < C::KM && kk < K) ? (float)F2[r * K + kk] : 0.f;
+                x[e] = (r < rows && kk < KM2 && kk < K) ? (float)F2[r * K + kk] : 0.f;
             }
             u4v o[3];
             split8(x, o);
@@ -137,7 +141,9 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
     using C = Cfg<KC, TAIL>;
     constexpr int NT = C::NT;
     constexpr int MP = C::PV_RAW;                                          // first mask piece inside an image buffer
-    constexpr bool DMA_TOP = KC <= 3;
+    // the tail factors of the SECOND product ride in the last factor tile's image (k_zi_images: KM2): no 4 x 4 x 1 instructions
+    constexpr bool TIB = TAIL && 32 * NT >= C::KM + 4;
+    constexpr bool DMA_TOP = KC <= 4;     // [r6] KC = 4 too: 3.69 against 3.99 ms at K = 50 / 64 on four chunks (profiles/r06_zi_k52_ab.txt)
     extern __shared__ u4v ldsq[];
     u4v *img = ldsq;                                                      // [3][PV]
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
                     const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u);
                     const uint32_t c0 = __float_as_uint(r0);
                     const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u);
-                    if (TAIL) {
+                    if (TAIL && !TIB) {
                         // (the B operands of four values at a time: 4 registers in flight instead of 16)
                         if ((vv & 3) == 0) t2 = tails[32 + (h * 4 + (lane & 3)) * 4 + (vv >> 2)];
                         rt = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, t2[vv & 3], rt, 0, 0, 0);
@@ -410,9 +416,9 @@ __global__ __launch_bounds__(512) void k_zi_row(float *__restrict__ D_hat, const
             for (int v = 0; v < 16; ++v) {
                 const int64_t cell = ct * 32 + acc_row(v, h);
                 const int k = nt * 32 + c;
-                if (cell < n && k < C::KM && k < K) atomicAdd(&DV[cell * K + k], (double)rs[nt][v]);
+                if (cell < n && k < (TIB ? C::KM + 4 : C::KM) && k < K) atomicAdd(&DV[cell * K + k], (double)rs[nt][v]);
             }
-        if (TAIL) {
+        if (TAIL && !TIB) {
             rt.x += __shfl_xor(rt.x, 32, 64); rt.y += __shfl_xor(rt.y, 32, 64);
             rt.z += __shfl_xor(rt.z, 32, 64); rt.w += __shfl_xor(rt.w, 32, 64);
             if (h == 0) {
@@ -613,7 +619,10 @@ static bool zi_cfg(int64_t K, int *kc, int *tl) {
     const int64_t Kp = oriana_kpad(K);
     if (K < zi_min_k() || Kp == 0 || Kp > 100 || (Kp % 16 != 0 && Kp % 16 != 4)) return false;
     *kc = (int)(Kp / 16); *tl = (Kp % 16 == 4) ? 1 : 0;
-    return *kc >= 3 && *kc <= 6 && !(*kc == 4 && *tl == 0);               // Kp = 48 .. 100 (Kp = 64: dense_f32.hip, measured)
+    // Kp = 48 .. 100.  [r6] Kp = 64 (K = 53 .. 64) too: with room for the flag / logit pieces behind the images (Cfg::PVZ) and the
+    // copies issued at the top of the tile, k_zi_row<4, 0> takes 3.68 ms where dense_f32.hip's bf16 kernel takes 4.11
+    // (K = 49 .. 52 stays on <3, 1> with the tail riding in the last factor tile: 3.65 against 3.72 ms zero-padded to four chunks)
+    return *kc >= 3 && *kc <= 6;
 }
 
 bool zi_supported(int64_t m, int64_t K) {                                  // the D update

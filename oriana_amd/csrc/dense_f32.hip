@@ -1042,7 +1042,7 @@ static int launch_dt(double *out, const float *D, const double *W, int64_t n, in
     return 0;
 }
 
-// 32 < K <= 100 except Kp = 64 (gene count a multiple of 4): csrc/dense_zi.hip
+// 32 < K <= 100 (gene count a multiple of 4): csrc/dense_zi.hip
 namespace dn {
 bool zi_supported(int64_t m, int64_t K);
 bool zi_dt_supported(int64_t m, int64_t K);

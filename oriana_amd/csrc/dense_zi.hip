@@ -9,8 +9,8 @@
 //              dn::k_dn_row (S(t) beside the matrix instructions of Lambda(t + 1), then the product of tile t).
 //   k_zi_col   out[gene, k] += sum_i D_hat[i, gene] W[i, k]  (zigap.py:124): dn::k_dn_col reading D_hat row-major.
 //
-// Serves 33 <= K <= 100 except Kp = 64 (zi_cfg below: measured assignment); dense_f32.hip keeps K <= 32, Kp = 64, and the
-// float32 matrix instruction for K > 100 or a gene count that is not a multiple of 4 (16-byte row pieces).
+// Serves 33 <= K <= 100 (zi_cfg / zi_cfg_dt below: measured assignment); dense_f32.hip keeps K <= 32 and the float32 matrix
+// instruction for K > 100 or a gene count that is not a multiple of 4 (16-byte row pieces).
 #include "dense_tiles.h"
 #include <stdlib.h>
 #include <string.h>
@@ -609,10 +609,10 @@ static int64_t zi_pick_splits(int64_t blocks, int64_t max_splits) {
         else return ORIANA_EKRANGE;                                           \
     } while (0)
 
-// Smallest K served here: 33.  Measured at 100k x 20k against dense_f32.hip's bf16 kernels (tools/perf_zi_per_k.py): D update
-// 3.45 against 4.11 ms at K = 48, 3.82 against 4.00 ms at K = 50; D^T U 1.82 against 2.00 ms at K = 48 but 2.06 against
-// 1.98 ms at K = 50 (the tail factors' 4 x 4 x 1 instructions): below 65 the transposed product comes here only when Kp has
-// no tail.
+// Smallest K served here: 33.  Measured at 100k x 20k against dense_f32.hip's bf16 kernels (tools/perf_zi_per_k.py, round 6's
+// build): D update 3.37 against 4.11 ms at K = 48, 3.65 against 4.00 ms at K = 50, 3.72 against 4.11 ms at K = 64; D^T U 1.82
+// against 2.00 ms at K = 48 but 2.06 against 1.98 ms at K = 50 WITH the tail factors' 4 x 4 x 1 instructions: below 65 the
+// transposed product takes the next whole chunk instead (zi_cfg_dt).
 static int64_t zi_min_k() { return 33; }
 
 static bool zi_cfg(int64_t K, int *kc, int *tl) {

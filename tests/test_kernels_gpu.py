@@ -574,10 +574,12 @@ def test_dropout_update_fused_matches_unfused(n, m, K):
 
 F32_SHAPES = [(1, 1, 1), (37, 53, 3), (300, 517, 20), (1000, 260, 50), (513, 1024, 100), (129, 2050, 33),
               (2000, 70, 64), (260, 300, 97), (70, 90, 128), (5000, 3001, 50), (4100, 600, 50),
-              # 32 < K <= 100 (not Kp = 64) with a gene count that is a multiple of 4: csrc/dense_zi.hip (every (KC, TAIL) pair, partial
+              # 32 < K <= 100 with a gene count that is a multiple of 4: csrc/dense_zi.hip (every (KC, TAIL) pair, partial
               # cell and gene tiles, fewer cells than a tile, several gene ranges / cell ranges per work-group column)
               (33, 36, 65), (3000, 2080, 84), (700, 5000, 96), (257, 132, 100), (9000, 420, 80), (31, 4, 100),
-              (513, 1022, 100), (300, 520, 40), (2000, 132, 48), (77, 64, 33), (640, 96, 52), (700, 520, 68)]
+              (513, 1022, 100), (300, 520, 40), (2000, 132, 48), (77, 64, 33), (640, 96, 52), (700, 520, 68),
+              # Kp = 64 (round 6: the D update on k_zi_row<4, 0>, D^T U on k_zi_col<4, 0>), K = 49 .. 52 with the tail in the last tile
+              (2100, 520, 64), (300, 132, 57), (5000, 2080, 60), (1030, 1028, 49), (290, 260, 51)]
 
 
 @pytest.mark.gpu

@@ -648,7 +648,8 @@ def test_dropout_sweep_fused_matches_float64(n, m, K, with_next, arithmetic):
     # Lambda carries K float32 roundings (<= 1e-7 K^0.5 |Lambda| absolute in the exponent), the sigmoid two more ulp
     lam_max = float((U @ V.t()).max())
     # (the six-product bf16 form of a float32 product drops terms below 2^-24 of it: a slightly wider bound there)
-    assert np.max(np.abs(d1 - d2) / np.maximum(d2, 1e-30) * (d2 > 1e-30)) < (6e-7 if arithmetic else 4e-7) * max(1.0, lam_max)
+    # (float32 instruction: measured 4.02e-7 |Lambda| at K = 60, |Lambda| = 102 -- 0.5 ulp x K^0.5 would be 4.6e-7)
+    assert np.max(np.abs(d1 - d2) / np.maximum(d2, 1e-30) * (d2 > 1e-30)) < (6e-7 if arithmetic else 5e-7) * max(1.0, lam_max)
     np.testing.assert_allclose(d1, d2, rtol=0, atol=3e-7)
     Xh = X.cpu().numpy()
     assert np.all(d1[Xh != 0] == 1.0)                                     # the overrides are exact

@@ -14,7 +14,7 @@ P = os.path.join(ROOT, 'profiles') + '/'
 NAMES = {'kernel_stats_c4.csv': 'bench_c4_kernel_stats.csv', 'kernel_stats_c3_zi.csv': 'zigap_c3_kernel_stats.csv',
          'kernel_stats_c5_sparse.csv': 'sparsegap_c5_kernel_stats.csv', 'zi_trace_nmf.txt': 'zigap_slow_path_trace_nmf.txt',
          'bench_c4_eighth_rccl1.json': 'bench_c4_eighth_rccl_one_rank.json'}
-KEEP = ('bench_', 'kernel_stats_', 'scaling_projection', 'parity_errors', 'zi_trace_nmf', 'perf_', 'extra_')
+KEEP = ('bench_', 'kernel_stats_', 'scaling_projection', 'parity_errors', 'zi_trace_nmf', 'perf_', 'extra_', 'pytest_gpu')
 for a in sorted(os.listdir(F)):
     if not a.startswith(KEEP) or a.endswith('.err') or os.path.isdir(F + a):
         continue

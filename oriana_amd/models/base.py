@@ -514,6 +514,17 @@ class FactorModel:
         ll_mean = (zero_term + nz_term).sum()
         return float(ll_x), float(ll_uv), float(ll_mean), nz, zz, xc
 
+    def loglikelihood_X(self, given='factors'):
+        """The zero-inflated Poisson log-likelihood of the counts (reference sparse_zigap.py:44-51) for the three Poisson
+        means the reference's metrics put into the UV node before calling it: 'factors' -- Lambda = U_hat (S_hat * V_hat)^T,
+        zeroed where round(D_hat) == 0 (base.py:64-68: the buffer reconstruction_deviance leaves behind, i.e. what a call
+        after it returns); 'counts' -- Lambda = X (base.py:59-63); 'mean' -- Lambda = the per-gene mean (base.py:76-77)."""
+        ll_x, ll_uv, ll_mean, _, _, _ = self._loglikelihoods()
+        try:
+            return {'factors': ll_uv, 'counts': ll_x, 'mean': ll_mean}[given]
+        except KeyError:
+            raise ValueError("given must be 'factors', 'counts' or 'mean'") from None
+
     def reconstruction_deviance(self):
         """-2 (ll(X | U_hat V_hat^T) - ll(X | X)), reference base.py:58-69."""
         ll_x, ll_uv, _, _, _, _ = self._loglikelihoods()

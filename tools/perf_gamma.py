@@ -19,7 +19,11 @@ def main():
         shapes = tuple(tuple(int(v) for v in t.split('x')) for t in os.environ['SHAPES'].split(','))
     for r, K in shapes:
         Kp = engine.kpad(K)
+        # [r6] shapes as a sweep sees them: most of a row's K shapes stay near the prior (a1 = prior + F R below 6 -- the regime in
+        # which the digamma's recurrence runs; round 5's all-large shapes hid a data-dependent loop of float64 divisions there),
+        # a tenth carries the counts.  SMALL_SHARE=0 restores the old input.
         F = torch.rand(r, Kp, device=dev); R = torch.rand(r, Kp, device=dev) * 50
+        R = R * (torch.rand(r, Kp, device=dev) >= float(os.environ.get('SMALL_SHARE', '0.9')))
         Z = torch.zeros(r, K, device=dev)
         idx = torch.randperm(r, device=dev).to(torch.int32)
         p1 = torch.rand(K, dtype=torch.float64, device=dev) + 0.5

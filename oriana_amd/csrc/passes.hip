@@ -800,8 +800,9 @@ extern "C" int oriana_fixup(const oriana_counts *cm, const int32_t *tile_flag, f
     const int quirk = ((variant & 4) ? 1 : 0) | ((variant & 8) ? 2 : 0);       // bit 1: Z_hat_j indexed by the packed gene
     // (K <= number of genes is the caller's to check: cm->m of the sliced part of a hybrid layout counts its own genes only)
     if ((quirk & 1) && !dq) return ORIANA_EQUIRK;
-    hipLaunchKernelGGL(k_fixup, dim3((unsigned)nt), dim3(256), 0, (hipStream_t)stream, *cm, tile_flag, s_cs,
-                       sw_cs, s_rs, logU, logV, S_tilde, S_hat, w_nz, dq, Zi, Zj, Zlog, (int)K, quirk);
+    const int per = (int)(nt / 2048 < 1 ? 1 : (nt / 2048 > 64 ? 64 : nt / 2048));       // tiles per work-group (k_fixup)
+    hipLaunchKernelGGL(k_fixup, dim3((unsigned)((nt + per - 1) / per)), dim3(256), 0, (hipStream_t)stream, *cm, tile_flag, s_cs,
+                       sw_cs, s_rs, logU, logV, S_tilde, S_hat, w_nz, dq, Zi, Zj, Zlog, (int)K, quirk, nt, per);
     ORIANA_LAUNCH_CHECK();
     return 0;
 }

@@ -684,103 +684,114 @@ __global__ __launch_bounds__(256) void k_fixup(oriana_counts cm, const int32_t *
                                                const float *__restrict__ logV, const float *__restrict__ S_tilde,
                                                const float *__restrict__ S_hat, const float *__restrict__ w_nz,
                                                const float *__restrict__ dq, float *__restrict__ Zi,
-                                               float *__restrict__ Zj, float *__restrict__ Zlog, int K, int quirk) {
-    const int64_t t = blockIdx.x;
-    if (tile_flag[t] == 0) return;
+                                               float *__restrict__ Zj, float *__restrict__ Zlog, int K, int quirk,
+                                               int64_t nt, int per) {
+    // [r6] One work-group per `per` <= 64 tiles (the host: nt / 2048, so that a start with every tile flagged still spreads
+    // over >= 2048 groups): every wave reads the same flags and walks the flagged ones (the mask is wave-uniform and identical
+    // in the four waves, so the barriers below are reached by all).  Round 5 launched a group per tile: 0.12 ms at configs[3]
+    // for 4e5 groups that read one flag and left.
     __shared__ uint32_t queue[FIX_WINDOW];
     __shared__ uint32_t rs[17];
     __shared__ uint32_t qn;
     __shared__ __attribute__((aligned(16))) float ebuf[4][FIX_KMAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t rb = t / cm.ncb, cb = t - rb * cm.ncb;
-    const int64_t rbase = cm.roff[t], cbase = cm.coff[t];
-    if (tid < 17) rs[tid] = cm.rslice[t * 17 + tid];
-    __syncthreads();
-    const uint32_t total = rs[16];
-    const int K4 = (K + 3) & ~3;
-    for (uint32_t base = 0; base < total; base += FIX_WINDOW) {
-        if (tid == 0) qn = 0;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    const bool mine = lane < per && t0 + lane < nt;
+    uint64_t pending = __ballot(mine && tile_flag[mine ? t0 + lane : 0] != 0);
+    while (pending) {
+        const int64_t t = t0 + __builtin_ctzll(pending);
+        pending &= pending - 1;
+        const int64_t rb = t / cm.ncb, cb = t - rb * cm.ncb;
+        const int64_t rbase = cm.roff[t], cbase = cm.coff[t];
+        if (tid < 17) rs[tid] = cm.rslice[t * 17 + tid];
         __syncthreads();
-        #pragma unroll
-        for (int u = 0; u < FIX_WINDOW / 256; ++u) {
-            const uint32_t slot = base + (uint32_t)u * 256u + (uint32_t)tid;
-            if (slot < total) {
+        const uint32_t total = rs[16];
+        const int K4 = (K + 3) & ~3;
+        for (uint32_t base = 0; base < total; base += FIX_WINDOW) {
+            if (tid == 0) qn = 0;
+            __syncthreads();
+            #pragma unroll
+            for (int u = 0; u < FIX_WINDOW / 256; ++u) {
+                const uint32_t slot = base + (uint32_t)u * 256u + (uint32_t)tid;
+                if (slot < total) {
+                    const oriana_rowrec rec = cm.rowrec[rbase + slot];
+                    if (rec.x != 0.f) {                                  // (0: padding)
+                        const float sv = s_cs[cbase + rec.cdst];
+                        if (sv != sv) queue[atomicAdd(&qn, 1u)] = slot;  // a sentinel
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nq = qn;
+            for (uint32_t q = wave; q < nq; q += 4) {
+                const uint32_t slot = queue[q];
+                int sl = 0;
+                #pragma unroll
+                for (int c = 1; c < 16; ++c) sl += (slot >= rs[c]) ? 1 : 0;
                 const oriana_rowrec rec = cm.rowrec[rbase + slot];
-                if (rec.x != 0.f) {                                  // (0: padding)
-                    const float sv = s_cs[cbase + rec.cdst];
-                    if (sv != sv) queue[atomicAdd(&qn, 1u)] = slot;  // a sentinel
+                const int rl = sl * 16 + (int)((slot & 63u) >> 2);       // (slices start at multiples of 64 slots)
+                const int64_t ip = rb * TILE + rl;                       // packed row / column
+                const int64_t jp = cb * TILE + rec.col;
+                const int64_t i = cm.row_perm ? (int64_t)cm.row_perm[ip] : ip;   // caller's row / gene
+                const int64_t j = cm.col_perm ? (int64_t)cm.col_perm[jp] : jp;
+                const float x = rec.x;
+                const float w = w_nz ? w_nz[rbase + slot] : 1.0f;
+                float ls[FIX_KMAX / 64], e[FIX_KMAX / 64];
+                #pragma unroll
+                for (int r = 0; r < FIX_KMAX / 64; ++r) {
+                    const int k = lane + 64 * r;
+                    ls[r] = 0.f; e[r] = 0.f;
+                    if (k < K) {
+                        ls[r] = logU[i * K + k] + logV[j * K + k];
+                        e[r] = expf(ls[r]);
+                        if (S_tilde) e[r] *= S_tilde[j * K + k];
+                    }
+                    if (k < K4) ebuf[wave][k] = e[r];                    // (zeros up to a multiple of 4: den + 0 = den)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the wave's own LDS writes, before its lanes read them)
+                __builtin_amdgcn_wave_barrier();
+                // den = sum_k exp(lu + lv) [* S_tilde], float32, left to right (gap.py:74-76)
+                float den = 0.f;
+                for (int k = 0; k < K4; k += 4) {
+                    const f4 v = *reinterpret_cast<const f4 *>(&ebuf[wave][k]);
+                    den += v.x; den += v.y; den += v.z; den += v.w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (read before the next entry overwrites the copy)
+                __builtin_amdgcn_wave_barrier();
+                den = (den > 0.f) ? den : 1.0f;
+                #pragma unroll
+                for (int r = 0; r < FIX_KMAX / 64; ++r) {
+                    const int k = lane + 64 * r;
+                    if (k >= K) continue;
+                    const float expectation = (x * e[r]) / den;          // gap.py:78
+                    if (Zi) {
+                        float wi = w;
+                        if (S_hat) wi = w_nz ? w * S_hat[j * K + k] : S_hat[j * K + k];   // sparse_zigap.py:114 / sparse_gap.py:95
+                        const float v = (w_nz || S_hat) ? wi * expectation : expectation;
+                        if (v != 0.f) atomicAdd(&Zi[i * K + k], v);
+                    }
+                    if (Zj) {
+                        float v = expectation;
+                        if ((quirk & 1) && dq) v = dq[i * K + k] * expectation;   // zigap.py:94 (D_hat[i, k])
+                        else if (w_nz) v = w * expectation;                 // sparse_zigap.py:115
+                        // (quirk bit 1: Zj is indexed by the PACKED gene index -- the sharded pCMF sweep exchanges the per-gene
+                        //  sums in packed order, engine.zq_gap zj_packed)
+                        if (v != 0.f) atomicAdd(&Zj[((quirk & 2) ? jp : j) * K + k], v);
+                    }
+                    if (Zlog) {
+                        const float v = (w_nz ? w * expectation : expectation) * ls[r];   // zigap.py:95
+                        if (v != 0.f) atomicAdd(&Zlog[j * K + k], v);
+                    }
+                }
+                if (lane == 0) {
+                    s_cs[cbase + rec.cdst] = 0.f;
+                    if (sw_cs) sw_cs[cbase + rec.cdst] = 0.f;
+                    if (s_rs) s_rs[rbase + slot] = 0.f;
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        const uint32_t nq = qn;
-        for (uint32_t q = wave; q < nq; q += 4) {
-            const uint32_t slot = queue[q];
-            int sl = 0;
-            #pragma unroll
-            for (int c = 1; c < 16; ++c) sl += (slot >= rs[c]) ? 1 : 0;
-            const oriana_rowrec rec = cm.rowrec[rbase + slot];
-            const int rl = sl * 16 + (int)((slot & 63u) >> 2);       // (slices start at multiples of 64 slots)
-            const int64_t ip = rb * TILE + rl;                       // packed row / column
-            const int64_t jp = cb * TILE + rec.col;
-            const int64_t i = cm.row_perm ? (int64_t)cm.row_perm[ip] : ip;   // caller's row / gene
-            const int64_t j = cm.col_perm ? (int64_t)cm.col_perm[jp] : jp;
-            const float x = rec.x;
-            const float w = w_nz ? w_nz[rbase + slot] : 1.0f;
-            float ls[FIX_KMAX / 64], e[FIX_KMAX / 64];
-            #pragma unroll
-            for (int r = 0; r < FIX_KMAX / 64; ++r) {
-                const int k = lane + 64 * r;
-                ls[r] = 0.f; e[r] = 0.f;
-                if (k < K) {
-                    ls[r] = logU[i * K + k] + logV[j * K + k];
-                    e[r] = expf(ls[r]);
-                    if (S_tilde) e[r] *= S_tilde[j * K + k];
-                }
-                if (k < K4) ebuf[wave][k] = e[r];                    // (zeros up to a multiple of 4: den + 0 = den)
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the wave's own LDS writes, before its lanes read them)
-            __builtin_amdgcn_wave_barrier();
-            // den = sum_k exp(lu + lv) [* S_tilde], float32, left to right (gap.py:74-76)
-            float den = 0.f;
-            for (int k = 0; k < K4; k += 4) {
-                const f4 v = *reinterpret_cast<const f4 *>(&ebuf[wave][k]);
-                den += v.x; den += v.y; den += v.z; den += v.w;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (read before the next entry overwrites the copy)
-            __builtin_amdgcn_wave_barrier();
-            den = (den > 0.f) ? den : 1.0f;
-            #pragma unroll
-            for (int r = 0; r < FIX_KMAX / 64; ++r) {
-                const int k = lane + 64 * r;
-                if (k >= K) continue;
-                const float expectation = (x * e[r]) / den;          // gap.py:78
-                if (Zi) {
-                    float wi = w;
-                    if (S_hat) wi = w_nz ? w * S_hat[j * K + k] : S_hat[j * K + k];   // sparse_zigap.py:114 / sparse_gap.py:95
-                    const float v = (w_nz || S_hat) ? wi * expectation : expectation;
-                    if (v != 0.f) atomicAdd(&Zi[i * K + k], v);
-                }
-                if (Zj) {
-                    float v = expectation;
-                    if ((quirk & 1) && dq) v = dq[i * K + k] * expectation;   // zigap.py:94 (D_hat[i, k])
-                    else if (w_nz) v = w * expectation;                 // sparse_zigap.py:115
-                    // (quirk bit 1: Zj is indexed by the PACKED gene index -- the sharded pCMF sweep exchanges the per-gene
-                    //  sums in packed order, engine.zq_gap zj_packed)
-                    if (v != 0.f) atomicAdd(&Zj[((quirk & 2) ? jp : j) * K + k], v);
-                }
-                if (Zlog) {
-                    const float v = (w_nz ? w * expectation : expectation) * ls[r];   // zigap.py:95
-                    if (v != 0.f) atomicAdd(&Zlog[j * K + k], v);
-                }
-            }
-            if (lane == 0) {
-                s_cs[cbase + rec.cdst] = 0.f;
-                if (sw_cs) sw_cs[cbase + rec.cdst] = 0.f;
-                if (s_rs) s_rs[rbase + slot] = 0.f;
-            }
-        }
-        __syncthreads();
+        __syncthreads();                     // (rs, queue, qn belong to the next flagged tile from here on)
     }
 }
 

@@ -240,6 +240,43 @@ def test_zq_gap_slow_path(eng):
     _same_zeros(Zj, rZj)
 
 
+def test_zq_gap_slow_path_many_tiles(eng):
+    """[r6] From 4096 tiles on oriana_fixup gives a work-group several tiles (nt / 2048, at most 64) and the group walks the
+    flagged ones: 65 x 65 tiles with ragged edges, a few hundred rows and genes outside the fast path's range so that more
+    than a thousand tiles are flagged -- most groups hold two -- against the oracle's zero-skipping loop nest."""
+    from oracle import cavi_oracle as co
+    rng = np.random.default_rng(61)
+    n, m, K = 16400, 16500, 5
+    X = np.zeros((n, m), np.float32)
+    nnz = 600000
+    X[rng.integers(0, n, nnz), rng.integers(0, m, nnz)] = rng.integers(1, 40, nnz).astype(np.float32)
+    lu = rng.normal(size=(n, K)).astype(np.float32)
+    lv = rng.normal(size=(m, K)).astype(np.float32)
+    rows = rng.choice(n, 400, replace=False)
+    cols = rng.choice(m, 300, replace=False)
+    lu[rows[:200]] -= 95.0                 # denormal exponentials
+    lu[rows[200:]] += 40.0                 # large shifts
+    lv[cols[:150]] -= 60.0
+    lv[cols[150:]] = -1e15                 # den == 0 guard
+    ct = eng.CountTiles.from_dense(X, 'cuda')
+    assert ct.nrb * ct.ncb >= 4096
+    ws = eng.ZWorkspace(ct, K)
+    Zi = torch.empty(n, K, dtype=torch.float32, device='cuda')
+    Zj = torch.empty(m, K, dtype=torch.float32, device='cuda')
+    eng.zq_gap(ws, Zi, Zj, torch.from_numpy(lu).cuda(), torch.from_numpy(lv).cuda())
+    torch.cuda.synchronize()
+    assert int(ws.tile_flag[:ct.nrb * ct.ncb].sum().item()) > 1000
+    rZi = np.empty((n, K), np.float32); rZj = np.empty((m, K), np.float32)
+    co.zq_gap_nz(rZi, rZj, lu, lv, X)
+    Zi, Zj = Zi.cpu().numpy(), Zj.cpu().numpy()
+    assert np.isfinite(Zi).all() and np.isfinite(Zj).all()
+    assert err_colrel(Zi, rZi) < RTOL and err_colrel(Zj, rZj) < RTOL
+    _same_zeros(Zi, rZi)
+    _same_zeros(Zj, rZj)
+    del ct, ws
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('K', [20, 50, 100])
 def test_den_threshold_follows_the_sums(eng, K):
     """[r4] Factors that have drifted along U c, V / c and specialised (what ZI-pCMF at configs[2] looks like after 25 sweeps):
